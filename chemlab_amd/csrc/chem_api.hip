@@ -1,0 +1,922 @@
+// chem_api.hip -- context, run loop and the C ABI of libchem_mi355.so (include/chem_mi355.h).
+//
+// One context == one GPU.  chem_run() enqueues the whole velocity-Verlet loop on one HIP
+// stream with no host round trip per step: the skin-triggered neighbour rebuild is decided on
+// the device (k_rebuild_decide) and the rebuild chain early-exits when it is not needed.
+// The host only synchronises at reaction steps (every `interval` steps) and at the end.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <memory>
+
+#include "chem_host.hpp"
+#include "md_kernels.hpp"
+
+namespace chem {
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      throw ChemError(CHEM_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <typename T> struct DBuf {
+  T* p = nullptr; size_t n = 0;
+  void alloc(size_t count) {
+    if (count <= n && p) return;
+    free();
+    HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T)));
+    n = count;
+  }
+  void free() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  ~DBuf() { free(); }
+  void upload(const std::vector<T>& h, hipStream_t s) {
+    alloc(h.size());
+    if (!h.empty()) HIPCHK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void download(std::vector<T>& h, size_t count, hipStream_t s) {
+    h.resize(count);
+    if (count) { HIPCHK(hipMemcpyAsync(h.data(), p, count * sizeof(T), hipMemcpyDeviceToHost, s)); }
+    HIPCHK(hipStreamSynchronize(s));
+  }
+};
+
+static inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------
+struct Ctx {
+  std::string err;
+  int device = 0, prec = 32;
+  double L[3] = {0, 0, 0}, rc = 0, skin = 0, dt = 0;
+  HostTopology top;
+  std::vector<double> pos0, vel0;  // staged particle data (tag order) until first upload
+  int ntypes = 1;
+  HostPairPot pp[CHEM_MAX_TYPES][CHEM_MAX_TYPES];
+  bool lang = false; double kT = 0, gamma = 0; uint64_t lang_seed = 0;
+  bool react_init = false, react_on = false;
+  int interval = 0, nearest = 1; uint64_t react_seed = 0;
+  std::vector<chem_reaction_desc> reactions;
+  std::vector<chem_event> events;
+  int64_t step = 0;
+  bool resort = true;
+  bool geom_dirty = true, particles_dirty = true, pair_dirty = true, bonded_dirty = true, excl_dirty = true, labels_dirty = true;
+  int nl_capacity_user = 0;
+  int opt_tpp = 0;          // 0 = automatic
+  int opt_time_pair = 0;    // HIP-event timing of every pair-force launch
+  int opt_fuse = 1;         // fused integrate2+integrate1
+  chem_timers tm{};
+  virtual ~Ctx() {}
+  virtual void run(int64_t nsteps) = 0;
+  virtual int64_t get_state(int what, void* out, int64_t cap) = 0;
+  virtual void observe(chem_obs* out) = 0;
+  virtual int64_t verlet_pairs(int64_t* out, int64_t cap) = 0;
+  virtual void modify_particle(int tag, int what, double value) = 0;
+  virtual void sync() = 0;
+};
+
+template <typename R> struct CtxT : Ctx {
+  using V4 = Vec4<R>;
+  hipStream_t stream = nullptr;
+  int n = 0;
+  DBuf<V4> x4, v4, f4, x4o, v4o, tab;
+  DBuf<int> tag, tago, rtag, state, res_id, mol_id;
+  DBuf<int4> img4, img4o;
+  DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
+  DBuf<int> nlist, nn;
+  int S = 0;
+  DBuf<int> excl_start, excl_list; int has_excl = 0;
+  DBuf<int> bstart; DBuf<BondedEntry> bent; DBuf<BondedParam> bpar; int64_t nbent = 0;
+  DBuf<PairCore<R>> pcore; DBuf<PairExt<R>> pext;
+  DBuf<DevCtl> ctl;
+  DBuf<double> eout, ekout, elist;
+  // reactions
+  DBuf<Candidate> cand, evout; int cand_cap = 0;
+  DBuf<int> st0, st1, asA, asB, evcount;
+  DBuf<unsigned long long> best1, best2;
+  DBuf<ReactSet> rs_dev;
+  Box<R> box{}; BoxD boxd{};
+  bool device_ready = false;
+  std::vector<hipEvent_t> ev;  // pair-kernel timing events (pairs)
+  size_t ev_used = 0;
+
+  CtxT() { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
+  ~CtxT() override {
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  void sync() override { HIPCHK(hipStreamSynchronize(stream)); }
+
+  // ---- uploads ------------------------------------------------------------------------
+  void setup_box() {
+    const double rl = rc + skin;
+    int nc[3]; bool cells = true;
+    for (int d = 0; d < 3; ++d) { nc[d] = (int)std::floor(L[d] / rl); if (nc[d] < 3) cells = false; }
+    for (int d = 0; d < 3; ++d) {
+      box.L[d] = (R)L[d]; box.invL[d] = (R)(1.0 / L[d]);
+      box.nc[d] = cells ? nc[d] : 0;
+      box.cell_inv[d] = (R)((cells ? nc[d] : 1) / L[d]);
+      boxd.L[d] = L[d]; boxd.invL[d] = 1.0 / L[d];
+    }
+    box.ncell = cells ? nc[0] * nc[1] * nc[2] : 1;
+  }
+
+  // cells, neighbour-list capacity and everything else that depends on box/cutoff/skin
+  void setup_geometry() {
+    setup_box();
+    cell_cnt.alloc(box.ncell + 1); cell_start.alloc(box.ncell + 1);
+    HIPCHK(hipMemsetAsync(cell_cnt.p, 0, sizeof(int) * (box.ncell + 1), stream));
+    const double vol = L[0] * L[1] * L[2], rl = rc + skin;
+    const double expect = 4.0 / 3.0 * M_PI * rl * rl * rl * n / vol;
+    int cap = nl_capacity_user > 0 ? nl_capacity_user : (int)(expect * 1.6 + 48);
+    cap = std::min(cap, std::max(n - 1, 1));
+    S = (cap + 15) / 16 * 16;
+    nlist.free(); nlist.alloc((size_t)n * S);
+    tm.nlist_capacity = S;
+    HIPCHK(hipStreamSynchronize(stream));
+    geom_dirty = false; resort = true;
+  }
+
+  void upload_particles() {
+    n = (int)top.n;
+    std::vector<V4> hx(n), hv(n);
+    std::vector<int> ht(n);
+    std::vector<int4> hi(n, make_int4(0, 0, 0, 0));
+    for (int t = 0; t < n; ++t) {
+      hx[t].x = (R)pos0[3 * t]; hx[t].y = (R)pos0[3 * t + 1]; hx[t].z = (R)pos0[3 * t + 2]; hx[t].w = (R)top.type[t];
+      hv[t].x = (R)vel0[3 * t]; hv[t].y = (R)vel0[3 * t + 1]; hv[t].z = (R)vel0[3 * t + 2]; hv[t].w = (R)top.mass[t];
+      ht[t] = t;
+    }
+    x4.upload(hx, stream); v4.upload(hv, stream); tag.upload(ht, stream); rtag.upload(ht, stream); img4.upload(hi, stream);
+    f4.alloc(n); x4o.alloc(n); v4o.alloc(n); tago.alloc(n); img4o.alloc(n);
+    HIPCHK(hipMemsetAsync(f4.p, 0, sizeof(V4) * n, stream));
+    cell_of.alloc(n); slot_of.alloc(n); perm.alloc(n); nn.alloc(n);
+    HIPCHK(hipMemsetAsync(nn.p, 0, sizeof(int) * n, stream));
+    ctl.alloc(1);
+    HIPCHK(hipMemsetAsync(ctl.p, 0, sizeof(DevCtl), stream));
+    eout.alloc(3 * (size_t)cdiv((long long)n * 64, 256) + 8);
+    ekout.alloc(4 * (size_t)cdiv(n, 256) + 8);
+    elist.alloc(CHEM_MAX_LISTS);
+    state.alloc(n); res_id.alloc(n); mol_id.alloc(n);
+    HIPCHK(hipStreamSynchronize(stream));
+    pos0.clear(); pos0.shrink_to_fit(); vel0.clear(); vel0.shrink_to_fit();
+    particles_dirty = false; labels_dirty = true; geom_dirty = true; resort = true; device_ready = true;
+  }
+
+  void upload_labels() {
+    state.upload(top.state, stream); res_id.upload(top.res_id, stream); mol_id.upload(top.mol_id, stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    labels_dirty = false;
+  }
+
+  void upload_pair() {
+    int nt = 1;
+    for (int t : top.type) nt = std::max(nt, t + 1);
+    for (int a = 0; a < CHEM_MAX_TYPES; ++a) for (int b = 0; b < CHEM_MAX_TYPES; ++b) if (pp[a][b].kind) nt = std::max(nt, std::max(a, b) + 1);
+    for (auto& r : reactions) { nt = std::max(nt, std::max(r.new_type_1, r.new_type_2) + 1); }
+    ntypes = nt;
+    std::vector<PairCore<R>> hc((size_t)nt * nt);
+    std::vector<PairExt<R>> he((size_t)nt * nt);
+    std::vector<V4> htab;
+    for (int a = 0; a < nt; ++a) for (int b = 0; b < nt; ++b) {
+      const HostPairPot& p = pp[a][b];
+      PairCore<R> c{(R)-1, 0, 0, 0}; PairExt<R> e{0, 0, 0, 0, 0, 0, 0, 0};
+      if (p.kind == 1) {
+        const double s6 = std::pow(p.sig, 6), s12 = s6 * s6;
+        c.rc2 = (R)(p.rc * p.rc); c.lj1 = (R)(48.0 * p.eps * s12); c.lj2 = (R)(24.0 * p.eps * s6); c.kind = (R)1;
+        e.e1 = (R)(4.0 * p.eps * s12); e.e2 = (R)(4.0 * p.eps * s6); e.shift = (R)p.shift;
+      } else if (p.kind == 2) {
+        c.rc2 = (R)(p.rc * p.rc); c.kind = (R)2;
+        e.r0 = (R)p.r0; e.inv_dr = (R)(1.0 / p.dr); e.toff = (int)htab.size(); e.nrow = (int)p.e.size();
+        for (size_t k = 0; k < p.e.size(); ++k) {
+          const double fk = p.f[k], ek = p.e[k];
+          const double fn = k + 1 < p.f.size() ? p.f[k + 1] : fk, en = k + 1 < p.e.size() ? p.e[k + 1] : ek;
+          V4 row; row.x = (R)fk; row.y = (R)(fn - fk); row.z = (R)ek; row.w = (R)(en - ek);
+          htab.push_back(row);
+        }
+      }
+      hc[(size_t)a * nt + b] = c; he[(size_t)a * nt + b] = e;
+    }
+    pcore.upload(hc, stream); pext.upload(he, stream); tab.upload(htab, stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    pair_dirty = false;
+  }
+
+  void upload_bonded() {
+    std::vector<int32_t> hs; std::vector<HBondedEntry> he; std::vector<HBondedParam> hp;
+    top.build_bonded(hs, he, hp);
+    static_assert(sizeof(HBondedEntry) == sizeof(BondedEntry) && sizeof(HBondedParam) == sizeof(BondedParam), "layout");
+    bstart.alloc(hs.size()); bent.alloc(he.size()); bpar.alloc(hp.size());
+    HIPCHK(hipMemcpyAsync(bstart.p, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (!he.empty()) HIPCHK(hipMemcpyAsync(bent.p, he.data(), he.size() * sizeof(BondedEntry), hipMemcpyHostToDevice, stream));
+    if (!hp.empty()) HIPCHK(hipMemcpyAsync(bpar.p, hp.data(), hp.size() * sizeof(BondedParam), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    nbent = (int64_t)he.size();
+    bonded_dirty = false;
+  }
+
+  void upload_excl() {
+    std::vector<int32_t> es, el;
+    top.build_excl(es, el);
+    excl_start.upload(es, stream); excl_list.upload(el, stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    has_excl = el.empty() ? 0 : 1;
+    excl_dirty = false; resort = true;
+  }
+
+  void flush_host_state() {
+    if (top.n <= 0 || !(L[0] > 0) || !(rc > 0)) throw ChemError(CHEM_ESTATE, "system incomplete: need box, cutoff and particles");
+    if (particles_dirty) upload_particles();
+    if (geom_dirty) setup_geometry();
+    if (labels_dirty) upload_labels();
+    if (pair_dirty) upload_pair();
+    if (bonded_dirty) upload_bonded();
+    if (excl_dirty) upload_excl();
+  }
+
+  // ---- rebuild chain (every kernel early-exits unless ctl->need_rebuild) ---------------
+  void launch_rebuild_chain() {
+    const int nb = cdiv(n, 256);
+    DevCtl* c = ctl.p;
+    hipLaunchKernelGGL(k_bin<R>, dim3(nb), dim3(256), 0, stream, n, x4.p, img4.p, box, cell_cnt.p, cell_of.p, slot_of.p, c);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream, box.ncell, cell_cnt.p, cell_start.p, c);
+    hipLaunchKernelGGL(k_place, dim3(nb), dim3(256), 0, stream, n, cell_of.p, slot_of.p, cell_start.p, perm.p, c);
+    hipLaunchKernelGGL(k_sort_cells, dim3(cdiv(box.ncell, 256)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p, tag.p, c);
+    hipLaunchKernelGGL(k_gather<R>, dim3(nb), dim3(256), 0, stream, n, perm.p, x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
+    hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, n, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, c);
+    const R rl2 = (R)((rc + skin) * (rc + skin));
+    if (box.nc[0] > 0)
+      hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(box.ncell), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
+                         excl_start.p, excl_list.p, has_excl, nlist.p, nn.p, S, c);
+    else
+      hipLaunchKernelGGL(k_nlist_brute<R>, dim3(cdiv(n, 4)), dim3(256), 0, stream, n, x4.p, tag.p, box, rl2, excl_start.p,
+                         excl_list.p, has_excl, nlist.p, nn.p, S, c);
+  }
+
+  void decide_and_rebuild() {
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1), 0, stream, ctl.p, 0.5 * skin);
+    launch_rebuild_chain();
+  }
+
+  DevCtl read_ctl() {
+    DevCtl h;
+    HIPCHK(hipMemcpyAsync(&h, ctl.p, sizeof(DevCtl), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return h;
+  }
+  template <typename F> void set_ctl_field(F DevCtl::*field, F value) {
+    DevCtl* base = nullptr;
+    size_t off = (size_t)((char*)&(base->*field) - (char*)base);
+    HIPCHK(hipMemcpyAsync((char*)ctl.p + off, &value, sizeof(F), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+  }
+
+  // forced synchronous rebuild (run() prologue, observe); grows the row stride on overflow
+  void rebuild_now() {
+    const double t0 = now_s();
+    for (int attempt = 0; attempt < 6; ++attempt) {
+      set_ctl_field(&DevCtl::force_rebuild, 1);
+      decide_and_rebuild();
+      DevCtl h = read_ctl();
+      if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil holds " + std::to_string(h.stage_overflow) + " particles, LDS tile capacity 1536: density too high for cell edge rc+skin");
+      if (!h.nl_overflow) { resort = false; tm.rebuild_wall_s += now_s() - t0; return; }
+      int newS = ((int)(h.nl_overflow * 1.25) + 31) / 16 * 16;
+      if (nl_capacity_user > 0) throw ChemError(CHEM_ENOSPC, "neighbour capacity " + std::to_string(S) + " too small, need " + std::to_string(h.nl_overflow));
+      S = std::min(newS, std::max((n + 15) / 16 * 16, 16));
+      nlist.free(); nlist.alloc((size_t)n * S);
+      tm.nlist_capacity = S;
+      set_ctl_field(&DevCtl::nl_overflow, 0);
+    }
+    throw ChemError(CHEM_ENOSPC, "neighbour list capacity could not be satisfied");
+  }
+
+  // ---- forces -------------------------------------------------------------------------
+  int pick_tpp() const {
+    if (opt_tpp > 0) return opt_tpp;
+    return n >= 400000 ? 8 : 16;
+  }
+
+  template <bool ENERGY> void launch_pair(V4* fdst, int tpp) {
+    const int nb = cdiv((long long)n * tpp, 256);
+    const double hs = 0.5 * skin;
+#define LP(T) hipLaunchKernelGGL((k_pair_force<R, T, ENERGY>), dim3(nb), dim3(256), 0, stream, n, x4.p, fdst, nlist.p, nn.p, S, box, \
+                                 pcore.p, pext.p, ntypes, tab.p, eout.p, hs, ctl.p)
+    switch (tpp) {
+      case 1: LP(1); break; case 2: LP(2); break; case 4: LP(4); break; case 8: LP(8); break;
+      case 16: LP(16); break; case 32: LP(32); break; default: LP(64); break;
+    }
+#undef LP
+  }
+
+  void compute_forces() {
+    const int tpp = pick_tpp();
+    const bool timed = opt_time_pair && ev_used + 2 <= ev.size();
+    if (timed) HIPCHK(hipEventRecord(ev[ev_used], stream));
+    launch_pair<false>(f4.p, tpp);
+    if (timed) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; }
+    if (nbent > 0)
+      hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
+                         bpar.p, boxd, elist.p);
+  }
+
+  LangevinP<R> lang_params(int64_t istep, int phase) const {
+    LangevinP<R> lp{};
+    lp.on = lang ? 1 : 0; lp.kT = kT; lp.gamma = gamma; lp.dt = dt; lp.seed = lang_seed; lp.step = (uint64_t)istep; lp.phase = (uint32_t)phase;
+    return lp;
+  }
+
+  template <int MODE> void launch_integrate(bool with_lang, bool storef, int64_t istep, int phase) {
+    const int nb = cdiv(n, 256);
+    LangevinP<R> lp = lang_params(istep, phase);
+    if (with_lang && storef)
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, ctl.p);
+    else if (with_lang)
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, ctl.p);
+    else
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, ctl.p);
+  }
+
+  void check_flags() {
+    DevCtl h = read_ctl();
+    tm.rebuilds = h.rebuild_count;
+    if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil exceeded the LDS tile capacity (" + std::to_string(h.stage_overflow) + " particles)");
+    if (h.nl_overflow) throw ChemError(CHEM_ENOSPC, "neighbour row overflow during run: needed " + std::to_string(h.nl_overflow) + ", capacity " + std::to_string(S) + " (chem_set_nlist_capacity)");
+    if (h.skin_violation) throw ChemError(CHEM_ESTATE, "internal: neighbour list used past skin/2");
+    if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
+  }
+
+  // ---- the hot call -------------------------------------------------------------------
+  void run(int64_t nsteps) override {
+    if (!(dt > 0)) throw ChemError(CHEM_ESTATE, "dt not set");
+    flush_host_state();
+    const double t0 = now_s();
+    if (opt_time_pair) {
+      const size_t want = (size_t)std::min<int64_t>(2 * (nsteps + 1), 16384);
+      while (ev.size() < want) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev.push_back(e); }
+      ev_used = 0;
+    }
+    if (resort) rebuild_now();
+    compute_forces();
+    if (lang) launch_integrate<0>(true, true, step, 0);  // thermalize: f += friction + noise, stored
+    bool need_int1 = true;
+    for (int64_t s = 0; s < nsteps; ++s) {
+      if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
+      decide_and_rebuild();
+      compute_forces();
+      const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
+      const bool last = (s == nsteps - 1);
+      if (last || react_due || !opt_fuse) {
+        launch_integrate<1>(lang, lang, step, 1);
+        ++step;
+        if (react_due) react_step();
+        need_int1 = true;
+      } else {
+        launch_integrate<3>(lang, false, step, 1);
+        ++step;
+      }
+    }
+    check_flags();
+    tm.run_wall_s += now_s() - t0;
+    tm.steps += nsteps;
+    if (opt_time_pair && ev_used) {
+      double ms = 0;
+      for (size_t k = 0; k + 1 < ev_used; k += 2) { float t = 0; HIPCHK(hipEventElapsedTime(&t, ev[k], ev[k + 1])); ms += t; }
+      tm.pair_kernel_ms = ms; tm.pair_kernel_launches = (int64_t)(ev_used / 2);
+    }
+  }
+
+  // ---- reactions ----------------------------------------------------------------------
+  void react_step() {
+    const double t0 = now_s();
+    tm.reaction_steps++;
+    if (reactions.empty()) return;
+    if (cand_cap == 0) {
+      cand_cap = std::max(8 * n, 1024);
+      cand.alloc(cand_cap); evout.alloc(cand_cap); st0.alloc(cand_cap); st1.alloc(cand_cap);
+      asA.alloc(n); asB.alloc(n); best1.alloc(n); best2.alloc(n); evcount.alloc(1); rs_dev.alloc(1);
+    }
+    ReactSet rs{};
+    rs.n = (int)reactions.size(); rs.seed = react_seed; rs.step = (uint64_t)step; rs.nearest = nearest;
+    ReactApplySet ras{};
+    for (int q = 0; q < rs.n; ++q) {
+      const chem_reaction_desc& d = reactions[q];
+      ReactionDev& r = rs.r[q];
+      r.type_1 = d.type_1; r.type_2 = d.type_2; r.delta_1 = d.delta_1; r.delta_2 = d.delta_2;
+      r.min1 = d.min_state_1; r.max1 = d.max_state_1; r.min2 = d.min_state_2; r.max2 = d.max_state_2;
+      r.intramolecular = d.intramolecular; r.intraresidual = d.intraresidual; r.active = d.active;
+      r.cut2 = d.cutoff * d.cutoff; r.mincut2 = d.min_cutoff * d.min_cutoff; r.prob = d.rate * dt * (double)interval;
+      ras.r[q] = ReactApply{d.delta_1, d.delta_2, d.new_type_1, d.new_type_2, d.new_mass_1, d.new_mass_2};
+    }
+    HIPCHK(hipMemcpyAsync(rs_dev.p, &rs, sizeof(ReactSet), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    set_ctl_field(&DevCtl::cand_count, 0);
+    hipLaunchKernelGGL(k_react_scan<R>, dim3(cdiv((long long)n * 8, 256)), dim3(256), 0, stream, n, x4.p, tag.p, nlist.p, nn.p, S, state.p,
+                       res_id.p, mol_id.p, boxd, rs_dev.p, cand.p, cand_cap, ctl.p);
+    DevCtl h = read_ctl();
+    if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
+    const int nc = h.cand_count;
+    if (nc == 0) { tm.reaction_wall_s += now_s() - t0; return; }
+    const int ncb = cdiv(nc, 256), npb = cdiv(n, 256);
+    hipLaunchKernelGGL(k_fill<int>, dim3(ncb), dim3(256), 0, stream, st0.p, 1, (size_t)nc);
+    for (int side = 0; side < 2; ++side) {
+      hipLaunchKernelGGL(k_fill<unsigned long long>, dim3(npb), dim3(256), 0, stream, best1.p, ~0ull, (size_t)n);
+      hipLaunchKernelGGL(k_fill<unsigned long long>, dim3(npb), dim3(256), 0, stream, best2.p, ~0ull, (size_t)n);
+      hipLaunchKernelGGL(k_res_min1, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, side, nearest, best1.p);
+      hipLaunchKernelGGL(k_res_min2, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, side, nearest, best1.p, best2.p);
+      hipLaunchKernelGGL(k_res_keep, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, side, nearest, best1.p, best2.p);
+    }
+    hipLaunchKernelGGL(k_fill<int>, dim3(npb), dim3(256), 0, stream, asA.p, -1, (size_t)n);
+    hipLaunchKernelGGL(k_fill<int>, dim3(npb), dim3(256), 0, stream, asB.p, -1, (size_t)n);
+    hipLaunchKernelGGL(k_res_index, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, asA.p, asB.p);
+    int* sin = st0.p; int* sout = st1.p;
+    for (int round = 0; round < 100000; ++round) {
+      set_ctl_field(&DevCtl::alive, 0);
+      hipLaunchKernelGGL(k_res_round, dim3(ncb), dim3(256), 0, stream, nc, cand.p, sin, sout, asA.p, asB.p, nearest, ctl.p);
+      std::swap(sin, sout);
+      if (read_ctl().alive == 0) break;
+    }
+    HIPCHK(hipMemsetAsync(evcount.p, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(k_react_apply<R>, dim3(ncb), dim3(256), 0, stream, nc, cand.p, sin, ras, state.p, rtag.p, x4.p, v4.p, evout.p, evcount.p);
+    int nev = 0;
+    HIPCHK(hipMemcpyAsync(&nev, evcount.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<Candidate> hev;
+    evout.download(hev, (size_t)nev, stream);
+    std::sort(hev.begin(), hev.end(), [](const Candidate& p, const Candidate& q) {
+      return std::make_pair(std::min(p.a, p.b), std::max(p.a, p.b)) < std::make_pair(std::min(q.a, q.b), std::max(q.a, q.b));
+    });
+    // host mirrors + topology
+    std::vector<std::pair<int32_t, int32_t>> newbonds;
+    bool types_changed = false;
+    for (auto& e : hev) {
+      const chem_reaction_desc& d = reactions[e.r];
+      top.state[e.a] += d.delta_1; top.state[e.b] += d.delta_2;
+      if (d.new_type_1 >= 0 && d.new_type_1 != top.type[e.a]) { top.type[e.a] = d.new_type_1; top.mass[e.a] = d.new_mass_1; top.q[e.a] = d.new_q_1; types_changed = true; }
+      if (d.new_type_2 >= 0 && d.new_type_2 != top.type[e.b]) { top.type[e.b] = d.new_type_2; top.mass[e.b] = d.new_mass_2; top.q[e.b] = d.new_q_2; types_changed = true; }
+      events.push_back(chem_event{step, top.id[e.a], top.id[e.b], e.r, 0, e.d2});
+      if (!d.is_virtual) {
+        int32_t t[2] = {e.a, e.b};
+        if (top.list_insert(top.lists[d.bond_list], t)) newbonds.emplace_back(e.a, e.b);
+      }
+    }
+    if (!newbonds.empty()) {
+      std::vector<int32_t> touched;
+      top.on_new_bonds(newbonds, touched);
+      res_id.upload(top.res_id, stream); mol_id.upload(top.mol_id, stream);
+      upload_bonded(); upload_excl();
+      resort = true;
+      set_ctl_field(&DevCtl::force_rebuild, 1);
+    } else if (types_changed) {
+      bool any_typed = false;
+      for (auto& l : top.lists) any_typed |= l.by_types != 0;
+      if (any_typed) upload_bonded();
+    }
+    tm.reaction_wall_s += now_s() - t0;
+  }
+
+  // ---- read-back ------------------------------------------------------------------------
+  int64_t get_state(int what, void* out, int64_t cap) override {
+    flush_host_state();
+    const int per = (what == CHEM_STATE_POS || what == CHEM_STATE_VEL || what == CHEM_STATE_FORCE || what == CHEM_STATE_IMAGE || what == CHEM_STATE_POS_UNFOLDED) ? 3 : 1;
+    if (cap < (int64_t)n * per) throw ChemError(CHEM_ENOSPC, "get_state: capacity");
+    std::vector<int> ht; tag.download(ht, n, stream);
+    double* d = (double*)out; int32_t* i32 = (int32_t*)out; int64_t* i64 = (int64_t*)out;
+    auto vec3 = [&](DBuf<V4>& src, bool want_w) {
+      std::vector<V4> h; src.download(h, n, stream);
+      for (int i = 0; i < n; ++i) {
+        const int t = ht[i];
+        if (want_w) d[t] = (double)h[i].w;
+        else { d[3 * t] = (double)h[i].x; d[3 * t + 1] = (double)h[i].y; d[3 * t + 2] = (double)h[i].z; }
+      }
+    };
+    switch (what) {
+      case CHEM_STATE_POS: case CHEM_STATE_POS_UNFOLDED: {
+        std::vector<V4> h; x4.download(h, n, stream);
+        std::vector<int4> hi; img4.download(hi, n, stream);
+        for (int i = 0; i < n; ++i) {
+          const int t = ht[i];
+          double p[3] = {(double)h[i].x, (double)h[i].y, (double)h[i].z};
+          const int im[3] = {hi[i].x, hi[i].y, hi[i].z};
+          for (int k = 0; k < 3; ++k) {
+            if (what == CHEM_STATE_POS) { double s = std::floor(p[k] / L[k]); p[k] -= s * L[k]; if (p[k] >= L[k]) p[k] -= L[k]; }
+            else p[k] += im[k] * L[k];
+            d[3 * t + k] = p[k];
+          }
+        }
+        break; }
+      case CHEM_STATE_VEL: vec3(v4, false); break;
+      case CHEM_STATE_FORCE: vec3(f4, false); break;
+      case CHEM_STATE_MASS: vec3(v4, true); break;
+      case CHEM_STATE_TYPE: { std::vector<V4> h; x4.download(h, n, stream); for (int i = 0; i < n; ++i) i32[ht[i]] = (int32_t)h[i].w; break; }
+      case CHEM_STATE_STATE: { std::vector<int> h; state.download(h, n, stream); std::copy(h.begin(), h.end(), i32); break; }
+      case CHEM_STATE_RESID: { std::vector<int> h; res_id.download(h, n, stream); std::copy(h.begin(), h.end(), i32); break; }
+      case CHEM_STATE_MOLID: { std::vector<int> h; mol_id.download(h, n, stream); for (int t = 0; t < n; ++t) i32[t] = (int32_t)top.id[h[t]]; break; }
+      case CHEM_STATE_ID: for (int t = 0; t < n; ++t) i64[t] = top.id[t]; break;
+      case CHEM_STATE_IMAGE: { std::vector<int4> hi; img4.download(hi, n, stream); for (int i = 0; i < n; ++i) { const int t = ht[i]; i32[3 * t] = hi[i].x; i32[3 * t + 1] = hi[i].y; i32[3 * t + 2] = hi[i].z; } break; }
+      default: throw ChemError(CHEM_EINVAL, "get_state: unknown selector");
+    }
+    return n;
+  }
+
+  void observe(chem_obs* out) override {
+    flush_host_state();
+    if (resort) rebuild_now();
+    std::memset(out, 0, sizeof(*out));
+    const int tpp = pick_tpp();
+    const int nb = cdiv((long long)n * tpp, 256);
+    launch_pair<true>(x4o.p, tpp);  // scratch force buffer: leaves f4 untouched
+    HIPCHK(hipMemsetAsync(elist.p, 0, sizeof(double) * CHEM_MAX_LISTS, stream));
+    if (nbent > 0)
+      hipLaunchKernelGGL((k_bonded<R, true>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n, x4.p, x4o.p, tag.p, rtag.p, bstart.p, bent.p,
+                         bpar.p, boxd, elist.p);
+    const int nkb = cdiv(n, 256);
+    hipLaunchKernelGGL(k_kinetic<R>, dim3(nkb), dim3(256), 0, stream, n, v4.p, ekout.p);
+    std::vector<double> he, hk, hl;
+    eout.download(he, 3 * (size_t)nb, stream); ekout.download(hk, 4 * (size_t)nkb, stream); elist.download(hl, CHEM_MAX_LISTS, stream);
+    double elj = 0, etab = 0, vir = 0, ek = 0, p[3] = {0, 0, 0};
+    for (int b = 0; b < nb; ++b) { elj += he[3 * b]; etab += he[3 * b + 1]; vir += he[3 * b + 2]; }
+    for (int b = 0; b < nkb; ++b) { ek += hk[4 * b]; p[0] += hk[4 * b + 1]; p[1] += hk[4 * b + 2]; p[2] += hk[4 * b + 3]; }
+    out->step = step; out->npart = n; out->ekin = ek; out->temperature = 2.0 * ek / (3.0 * n);
+    out->epot_lj = elj; out->epot_tab = etab; out->virial_nb = vir;
+    for (int k = 0; k < 3; ++k) out->momentum[k] = p[k];
+    for (size_t l = 0; l < top.lists.size(); ++l) { out->epot_list[l] = hl[l]; out->list_size[l] = top.lists[l].size(); }
+  }
+
+  int64_t verlet_pairs(int64_t* out, int64_t cap) override {
+    flush_host_state();
+    if (resort) rebuild_now();
+    std::vector<int> hn, ht, hl;
+    nn.download(hn, n, stream); tag.download(ht, n, stream); nlist.download(hl, (size_t)n * S, stream);
+    std::vector<std::pair<int64_t, int64_t>> pr;
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < hn[i]; ++k) {
+        const int a = ht[i], b = ht[hl[(size_t)i * S + k]];
+        pr.emplace_back(top.id[std::min(a, b)], top.id[std::max(a, b)]);
+      }
+    std::sort(pr.begin(), pr.end());
+    pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
+    const int64_t m = (int64_t)pr.size();
+    if (!out) return m;
+    if (cap < m) throw ChemError(CHEM_ENOSPC, "verlet_pairs: capacity");
+    for (int64_t k = 0; k < m; ++k) { out[2 * k] = pr[k].first; out[2 * k + 1] = pr[k].second; }
+    return m;
+  }
+
+  void modify_particle(int t, int what, double value) override {
+    if (!device_ready || particles_dirty) return;  // host mirror only; uploaded later
+    int idx = 0;
+    HIPCHK(hipMemcpyAsync(&idx, rtag.p + t, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (what == CHEM_STATE_TYPE) { R w = (R)value; HIPCHK(hipMemcpyAsync(&x4.p[idx].w, &w, sizeof(R), hipMemcpyHostToDevice, stream)); }
+    else if (what == CHEM_STATE_MASS) { R w = (R)value; HIPCHK(hipMemcpyAsync(&v4.p[idx].w, &w, sizeof(R), hipMemcpyHostToDevice, stream)); }
+    else if (what == CHEM_STATE_STATE) { int w = (int)value; HIPCHK(hipMemcpyAsync(state.p + t, &w, sizeof(int), hipMemcpyHostToDevice, stream)); }
+    else if (what == CHEM_STATE_RESID) { int w = (int)value; HIPCHK(hipMemcpyAsync(res_id.p + t, &w, sizeof(int), hipMemcpyHostToDevice, stream)); }
+    HIPCHK(hipStreamSynchronize(stream));
+  }
+};
+
+static std::string g_create_error;
+
+}  // namespace chem
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+using namespace chem;
+
+struct chem_ctx { std::unique_ptr<Ctx> c; };
+
+#define CTX (*ctx->c)
+#define API_BEGIN try {
+#define API_END(ctxp)                                                                  \
+  } catch (const ChemError& e) { (ctxp)->c->err = e.what(); return e.code; }           \
+    catch (const std::exception& e) { (ctxp)->c->err = e.what(); return CHEM_EINVAL; }
+#define REQUIRE(cond, code, msg) do { if (!(cond)) throw ChemError((code), (msg)); } while (0)
+
+extern "C" {
+
+int chem_abi_version(void) { return CHEM_ABI_VERSION; }
+
+chem_ctx* chem_create(int device_id, int precision) {
+  try {
+    if (precision != CHEM_PREC_F32 && precision != CHEM_PREC_F64) throw ChemError(CHEM_EINVAL, "precision must be 32 or 64");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw ChemError(CHEM_EDEVICE, "no HIP device available (libchem_mi355 has no CPU fall-back)");
+    if (device_id < 0 || device_id >= ndev) throw ChemError(CHEM_EINVAL, "device id out of range");
+    HIPCHK(hipSetDevice(device_id));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device_id));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+      throw ChemError(CHEM_EDEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    auto* h = new chem_ctx();
+    if (precision == CHEM_PREC_F32) h->c.reset(new CtxT<float>()); else h->c.reset(new CtxT<double>());
+    h->c->device = device_id; h->c->prec = precision;
+    return h;
+  } catch (const std::exception& e) { g_create_error = e.what(); return nullptr; }
+}
+
+void chem_destroy(chem_ctx* ctx) { delete ctx; }
+const char* chem_last_error(chem_ctx* ctx) { return ctx ? ctx->c->err.c_str() : g_create_error.c_str(); }
+
+int chem_set_box(chem_ctx* ctx, const double L[3]) {
+  API_BEGIN
+  for (int d = 0; d < 3; ++d) { REQUIRE(L[d] > 0, CHEM_EINVAL, "box edge must be positive"); CTX.L[d] = L[d]; }
+  CTX.geom_dirty = true; CTX.resort = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_set_cutoff(chem_ctx* ctx, double max_cutoff, double skin) {
+  API_BEGIN
+  REQUIRE(max_cutoff > 0 && skin >= 0, CHEM_EINVAL, "cutoff must be > 0 and skin >= 0");
+  CTX.rc = max_cutoff; CTX.skin = skin; CTX.geom_dirty = true; CTX.resort = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_set_dt(chem_ctx* ctx, double dt) { API_BEGIN REQUIRE(dt > 0, CHEM_EINVAL, "dt"); CTX.dt = dt; return 0; API_END(ctx) }
+
+int chem_set_particles(chem_ctx* ctx, int64_t n, const int64_t* id, const int32_t* type, const double* pos, const double* vel,
+                       const double* mass, const double* q, const int32_t* state, const int32_t* res_id) {
+  API_BEGIN
+  REQUIRE(n > 0 && id && type && pos && mass, CHEM_EINVAL, "set_particles: null or empty input");
+  REQUIRE(n < (1ll << 28), CHEM_EINVAL, "set_particles: too many particles for one context");
+  Ctx& c = CTX; HostTopology& t = c.top;
+  std::vector<int64_t> order(n);
+  for (int64_t i = 0; i < n; ++i) order[i] = i;
+  bool sorted = true;
+  for (int64_t i = 1; i < n; ++i) if (id[i] <= id[i - 1]) { sorted = false; break; }
+  if (!sorted) std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return id[a] < id[b]; });
+  t.n = n; t.id.resize(n); t.type.resize(n); t.state.resize(n); t.res_id.resize(n); t.mol_id.resize(n); t.mass.resize(n); t.q.resize(n);
+  t.graph.assign(n, {}); t.excl.assign(n, {}); t.n_excl_pairs = 0; t.id2tag.clear();
+  for (auto& l : t.lists) { l.ent.clear(); l.seen.clear(); }
+  c.pos0.resize(3 * n); c.vel0.assign(3 * n, 0.0);
+  t.contiguous = true; t.id0 = id[order[0]];
+  for (int64_t k = 0; k < n; ++k) {
+    const int64_t s = order[k];
+    REQUIRE(k == 0 || id[s] != t.id[k - 1], CHEM_EINVAL, "duplicate particle id");
+    REQUIRE(type[s] >= 0 && type[s] < CHEM_MAX_TYPES, CHEM_EINVAL, "particle type out of range [0,16)");
+    REQUIRE(mass[s] > 0, CHEM_EINVAL, "particle mass must be positive");
+    t.id[k] = id[s]; if (id[s] != t.id0 + k) t.contiguous = false;
+    t.type[k] = type[s]; t.mass[k] = mass[s]; t.q[k] = q ? q[s] : 0.0;
+    t.state[k] = state ? state[s] : 0; t.res_id[k] = res_id ? res_id[s] : (int32_t)id[s]; t.mol_id[k] = (int32_t)k;
+    for (int d = 0; d < 3; ++d) { c.pos0[3 * k + d] = pos[3 * s + d]; if (vel) c.vel0[3 * k + d] = vel[3 * s + d]; }
+  }
+  if (!t.contiguous) for (int64_t k = 0; k < n; ++k) t.id2tag[t.id[k]] = (int32_t)k;
+  c.particles_dirty = c.pair_dirty = c.bonded_dirty = c.excl_dirty = c.labels_dirty = true; c.resort = true;
+  c.step = 0; c.events.clear();
+  return 0;
+  API_END(ctx)
+}
+
+int chem_modify_particle(chem_ctx* ctx, int64_t id, int what, double value) {
+  API_BEGIN
+  Ctx& c = CTX; const int t = c.top.tag_of(id);
+  REQUIRE(t >= 0, CHEM_EINVAL, "modify_particle: unknown id");
+  if (what == CHEM_STATE_TYPE) { REQUIRE(value >= 0 && value < CHEM_MAX_TYPES, CHEM_EINVAL, "type"); c.top.type[t] = (int)value; c.pair_dirty = true; c.bonded_dirty = true; }
+  else if (what == CHEM_STATE_STATE) c.top.state[t] = (int)value;
+  else if (what == CHEM_STATE_MASS) { REQUIRE(value > 0, CHEM_EINVAL, "mass"); c.top.mass[t] = value; }
+  else if (what == CHEM_STATE_RESID) c.top.res_id[t] = (int)value;
+  else throw ChemError(CHEM_EINVAL, "modify_particle: selector");
+  c.modify_particle(t, what, value);
+  return 0;
+  API_END(ctx)
+}
+
+int chem_set_exclusions(chem_ctx* ctx, int64_t n, const int64_t* p) {
+  API_BEGIN
+  HostTopology& t = CTX.top;
+  REQUIRE(t.n > 0, CHEM_ESTATE, "set particles before exclusions");
+  for (auto& r : t.excl) r.clear();
+  t.n_excl_pairs = 0;
+  for (int64_t k = 0; k < n; ++k) {
+    const int a = t.tag_of(p[2 * k]), b = t.tag_of(p[2 * k + 1]);
+    REQUIRE(a >= 0 && b >= 0, CHEM_EINVAL, "exclusion: unknown particle id");
+    t.exclude(a, b);
+  }
+  CTX.excl_dirty = true; CTX.resort = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_nb_lj(chem_ctx* ctx, int t1, int t2, double eps, double sig, double rc, int shift_auto) {
+  API_BEGIN
+  REQUIRE(t1 >= 0 && t2 >= 0 && t1 < CHEM_MAX_TYPES && t2 < CHEM_MAX_TYPES, CHEM_EINVAL, "nb_lj: type out of range");
+  HostPairPot p; p.kind = (sig > 0 && rc > 0) ? 1 : 0; p.eps = eps; p.sig = sig; p.rc = rc;
+  if (p.kind && shift_auto) { const double s2 = sig * sig / (rc * rc), s6 = s2 * s2 * s2; p.shift = -4.0 * eps * (s6 * s6 - s6); }
+  CTX.pp[t1][t2] = p; CTX.pp[t2][t1] = p; CTX.pair_dirty = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_nb_table(chem_ctx* ctx, int t1, int t2, int64_t nrow, double r0, double dr, const double* e, const double* f, double rc) {
+  API_BEGIN
+  REQUIRE(t1 >= 0 && t2 >= 0 && t1 < CHEM_MAX_TYPES && t2 < CHEM_MAX_TYPES, CHEM_EINVAL, "nb_table: type out of range");
+  REQUIRE(nrow >= 2 && dr > 0 && e && f && rc > 0, CHEM_EINVAL, "nb_table: need >=2 rows, dr>0");
+  HostPairPot p; p.kind = 2; p.rc = rc; p.r0 = r0; p.dr = dr; p.e.assign(e, e + nrow); p.f.assign(f, f + nrow);
+  CTX.pp[t1][t2] = p; CTX.pp[t2][t1] = p; CTX.pair_dirty = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_list_create(chem_ctx* ctx, int arity, int kind, int by_types) {
+  API_BEGIN
+  REQUIRE(arity >= 2 && arity <= 4, CHEM_EINVAL, "list arity must be 2, 3 or 4");
+  const bool ok = (arity == 2 && (kind == CHEM_POT_HARMONIC || kind == CHEM_POT_FENE)) ||
+                  (arity == 3 && (kind == CHEM_POT_ANG_HARMONIC || kind == CHEM_POT_ANG_COSINE)) ||
+                  (arity == 4 && (kind == CHEM_POT_DIH_NCOS || kind == CHEM_POT_DIH_RB));
+  REQUIRE(ok, CHEM_ENOTIMPL, "potential kind not supported for this arity");
+  REQUIRE((int)CTX.top.lists.size() < CHEM_MAX_LISTS, CHEM_ENOSPC, "too many lists");
+  HostList l; l.arity = arity; l.kind = kind; l.by_types = by_types ? 1 : 0;
+  CTX.top.lists.push_back(std::move(l));
+  return (int)CTX.top.lists.size() - 1;
+  API_END(ctx)
+}
+
+int chem_list_add(chem_ctx* ctx, int list, int64_t n, const int64_t* ids) {
+  API_BEGIN
+  HostTopology& t = CTX.top;
+  REQUIRE(list >= 0 && list < (int)t.lists.size(), CHEM_EINVAL, "list handle");
+  REQUIRE(t.n > 0, CHEM_ESTATE, "set particles before list entries");
+  HostList& l = t.lists[list];
+  std::vector<std::pair<int32_t, int32_t>> nb;
+  for (int64_t e = 0; e < n; ++e) {
+    int32_t tg[4];
+    for (int k = 0; k < l.arity; ++k) { tg[k] = t.tag_of(ids[e * l.arity + k]); REQUIRE(tg[k] >= 0, CHEM_EINVAL, "list_add: unknown particle id"); }
+    if (t.list_insert(l, tg) && l.arity == 2) nb.emplace_back(tg[0], tg[1]);
+  }
+  for (auto& e : nb) t.graph_add(e.first, e.second);
+  std::vector<int32_t> touched;
+  for (auto& e : nb) if (t.mol_id[e.first] != t.mol_id[e.second]) t.merge_cluster(e.first, e.second, false, touched);
+  CTX.bonded_dirty = true; CTX.labels_dirty = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_list_set_params(chem_ctx* ctx, int list, int t1, int t2, int t3, int t4, const double* p, int np) {
+  API_BEGIN
+  HostTopology& t = CTX.top;
+  REQUIRE(list >= 0 && list < (int)t.lists.size() && p && np >= 1 && np <= CHEM_MAX_POT_PARAMS, CHEM_EINVAL, "list_set_params");
+  HostList& l = t.lists[list];
+  std::array<double, CHEM_MAX_POT_PARAMS> v{};
+  std::copy(p, p + np, v.begin());
+  if (!l.by_types) { l.plain = v; l.has_plain = true; }
+  else {
+    int tt[4] = {t1, t2, t3, t4};
+    std::array<int, 4> key{-1, -1, -1, -1};
+    for (int k = 0; k < l.arity; ++k) { REQUIRE(tt[k] >= 0 && tt[k] < CHEM_MAX_TYPES, CHEM_EINVAL, "type tuple"); key[k] = tt[k]; }
+    l.typed[key] = v;
+  }
+  CTX.bonded_dirty = true;
+  return 0;
+  API_END(ctx)
+}
+
+int64_t chem_get_list(chem_ctx* ctx, int list, int64_t* out, int64_t cap) {
+  API_BEGIN
+  HostTopology& t = CTX.top;
+  REQUIRE(list >= 0 && list < (int)t.lists.size(), CHEM_EINVAL, "list handle");
+  const HostList& l = t.lists[list];
+  if (!out) return l.size();
+  REQUIRE(cap >= l.size(), CHEM_ENOSPC, "get_list: capacity");
+  for (size_t k = 0; k < l.ent.size(); ++k) out[k] = t.id[l.ent[k]];
+  return l.size();
+  API_END(ctx)
+}
+
+int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t seed) {
+  API_BEGIN
+  CTX.lang = gamma > 0 && kT >= 0; CTX.kT = kT; CTX.gamma = gamma; CTX.lang_seed = seed;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_reaction_init(chem_ctx* ctx, int interval, int nearest, int max_per_interval, uint64_t seed) {
+  API_BEGIN
+  REQUIRE(interval > 0, CHEM_EINVAL, "reaction interval must be positive");
+  REQUIRE(max_per_interval <= 0, CHEM_ENOTIMPL, "max_per_interval is outside the hot-path scope (SURVEY f-4)");
+  CTX.react_init = true; CTX.interval = interval; CTX.nearest = nearest ? 1 : 0; CTX.react_seed = seed;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_reaction_add(chem_ctx* ctx, const chem_reaction_desc* d) {
+  API_BEGIN
+  Ctx& c = CTX;
+  REQUIRE(c.react_init, CHEM_ESTATE, "chem_reaction_init first");
+  REQUIRE(d, CHEM_EINVAL, "null descriptor");
+  REQUIRE((int)c.reactions.size() < CHEM_MAX_REACTIONS, CHEM_ENOSPC, "too many reactions");
+  REQUIRE(d->type_1 >= 0 && d->type_1 < CHEM_MAX_TYPES && d->type_2 >= 0 && d->type_2 < CHEM_MAX_TYPES, CHEM_EINVAL, "reaction types");
+  REQUIRE(d->new_type_1 < CHEM_MAX_TYPES && d->new_type_2 < CHEM_MAX_TYPES, CHEM_EINVAL, "reaction new types");
+  REQUIRE(d->cutoff > 0 && d->cutoff <= c.rc + 1e-12, CHEM_EINVAL, "reaction cutoff must be in (0, max_cutoff]: candidates come from the Verlet list");
+  if (!d->is_virtual) REQUIRE(d->bond_list >= 0 && d->bond_list < (int)c.top.lists.size() && c.top.lists[d->bond_list].arity == 2, CHEM_EINVAL, "reaction bond_list must be an arity-2 list");
+  if (d->new_type_1 >= 0) REQUIRE(d->new_mass_1 > 0, CHEM_EINVAL, "new_mass_1");
+  if (d->new_type_2 >= 0) REQUIRE(d->new_mass_2 > 0, CHEM_EINVAL, "new_mass_2");
+  c.reactions.push_back(*d); c.pair_dirty = true;
+  return (int)c.reactions.size() - 1;
+  API_END(ctx)
+}
+
+int chem_topology_register(chem_ctx* ctx, int arity, int list, const int32_t* types) {
+  API_BEGIN
+  HostTopology& t = CTX.top;
+  REQUIRE(list >= 0 && list < (int)t.lists.size() && t.lists[list].arity == arity && types, CHEM_EINVAL, "topology_register");
+  std::array<int, 4> key{-1, -1, -1, -1};
+  for (int k = 0; k < arity; ++k) key[k] = types[k];
+  t.lists[list].registered.push_back(key);
+  return 0;
+  API_END(ctx)
+}
+
+int chem_reactions_enable(chem_ctx* ctx, int on) { API_BEGIN CTX.react_on = on != 0; return 0; API_END(ctx) }
+
+int chem_reaction_set_rate(chem_ctx* ctx, int r, double rate) {
+  API_BEGIN
+  REQUIRE(r >= 0 && r < (int)CTX.reactions.size(), CHEM_EINVAL, "reaction index");
+  CTX.reactions[r].rate = rate;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_run(chem_ctx* ctx, int64_t nsteps) {
+  API_BEGIN
+  REQUIRE(nsteps >= 0, CHEM_EINVAL, "nsteps");
+  CTX.run(nsteps);
+  return 0;
+  API_END(ctx)
+}
+
+int64_t chem_num_particles(chem_ctx* ctx) { return ctx->c->top.n; }
+int64_t chem_get_step(chem_ctx* ctx) { return ctx->c->step; }
+
+int64_t chem_get_state(chem_ctx* ctx, int what, void* out, int64_t cap) {
+  API_BEGIN
+  REQUIRE(out, CHEM_EINVAL, "null output");
+  return CTX.get_state(what, out, cap);
+  API_END(ctx)
+}
+
+int64_t chem_get_events(chem_ctx* ctx, chem_event* out, int64_t cap) {
+  API_BEGIN
+  const int64_t n = (int64_t)CTX.events.size();
+  if (!out) return n;
+  REQUIRE(cap >= n, CHEM_ENOSPC, "get_events: capacity");
+  std::copy(CTX.events.begin(), CTX.events.end(), out);
+  return n;
+  API_END(ctx)
+}
+
+int64_t chem_get_exclusions(chem_ctx* ctx, int64_t* out, int64_t cap) {
+  API_BEGIN
+  HostTopology& t = CTX.top;
+  if (!out) return t.n_excl_pairs;
+  REQUIRE(cap >= t.n_excl_pairs, CHEM_ENOSPC, "get_exclusions: capacity");
+  int64_t k = 0;
+  for (int64_t a = 0; a < t.n; ++a) for (int32_t b : t.excl[a]) if (b > a) { out[2 * k] = t.id[a]; out[2 * k + 1] = t.id[b]; ++k; }
+  return k;
+  API_END(ctx)
+}
+
+int64_t chem_get_verlet_pairs(chem_ctx* ctx, int64_t* out, int64_t cap) { API_BEGIN return CTX.verlet_pairs(out, cap); API_END(ctx) }
+
+int chem_observe(chem_ctx* ctx, chem_obs* out) { API_BEGIN REQUIRE(out, CHEM_EINVAL, "null output"); CTX.observe(out); return 0; API_END(ctx) }
+
+int chem_get_timers(chem_ctx* ctx, chem_timers* out) {
+  API_BEGIN
+  REQUIRE(out, CHEM_EINVAL, "null output");
+  *out = CTX.tm;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_device_sync(chem_ctx* ctx) { API_BEGIN CTX.sync(); return 0; API_END(ctx) }
+
+int chem_set_nlist_capacity(chem_ctx* ctx, int m) { API_BEGIN REQUIRE(m >= 0, CHEM_EINVAL, "capacity"); CTX.nl_capacity_user = m; CTX.geom_dirty = true; return 0; API_END(ctx) }
+
+int chem_set_option(chem_ctx* ctx, const char* name, double value) {
+  API_BEGIN
+  const std::string k = name ? name : "";
+  if (k == "tpp") { const int v = (int)value; REQUIRE(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64, CHEM_EINVAL, "tpp must be a power of two <= 64"); CTX.opt_tpp = v; }
+  else if (k == "time_pair_kernel") CTX.opt_time_pair = value != 0;
+  else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
+  else throw ChemError(CHEM_EINVAL, "unknown option " + k);
+  return 0;
+  API_END(ctx)
+}
+
+int chem_comm_unique_id(char uid[128]) { (void)uid; return CHEM_ENOTIMPL; }
+int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], const char uid[128]) {
+  API_BEGIN
+  (void)rank; (void)node_grid; (void)uid;
+  if (nranks == 1) return 0;
+  throw ChemError(CHEM_ENOTIMPL, "multi-GPU domain decomposition is not built yet");
+  API_END(ctx)
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+// chem_host.hpp -- host-side state of one context: particle mirrors, bonded lists, the
+// topology manager (bond graph, angle/dihedral spawning, cluster labels) and the dynamic
+// exclusion list.  Pure C++, no device code; the device back end consumes the CSR tables
+// built here.  Events (new bonds) are rare compared to MD steps, so this irregular graph
+// work stays on the host (SURVEY.md 7 "Hard parts").
+//
+// Reference call sites: TopologyManager / DynamicExcludeList wiring,
+// src/start_simulation.py:189,211-212,378-441; FixedPair/Triple/QuadrupleList construction,
+// src/chemlab/gromacs_topology.py:949-961,1086-1096,1206-1224.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/chem_mi355.h"
+
+namespace chem {
+
+struct ChemError : std::runtime_error {
+  int code;
+  ChemError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+struct TupleKey {
+  uint64_t a, b;
+  bool operator==(const TupleKey& o) const { return a == o.a && b == o.b; }
+};
+struct TupleKeyHash {
+  size_t operator()(const TupleKey& k) const { return (size_t)(k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0x7F4A7C15ull + (k.a << 6))); }
+};
+
+// orientation-free key of a tuple of tags
+inline TupleKey tuple_key(const int32_t* t, int arity) {
+  int32_t f[4] = {-1, -1, -1, -1}, r[4] = {-1, -1, -1, -1};
+  for (int k = 0; k < arity; ++k) { f[k] = t[k]; r[arity - 1 - k] = t[k]; }
+  bool use_f = true;
+  for (int k = 0; k < arity; ++k) { if (f[k] != r[k]) { use_f = f[k] < r[k]; break; } }
+  const int32_t* c = use_f ? f : r;
+  return {((uint64_t)(uint32_t)c[0] << 32) | (uint32_t)c[1], ((uint64_t)(uint32_t)c[2] << 32) | (uint32_t)c[3]};
+}
+
+struct HostList {
+  int arity = 2, kind = 0, by_types = 0;
+  std::vector<int32_t> ent;  // arity tags per entry
+  std::unordered_set<TupleKey, TupleKeyHash> seen;
+  bool has_plain = false;
+  std::array<double, CHEM_MAX_POT_PARAMS> plain{};
+  std::map<std::array<int, 4>, std::array<double, CHEM_MAX_POT_PARAMS>> typed;
+  std::vector<std::array<int, 4>> registered;
+  int64_t size() const { return (int64_t)ent.size() / arity; }
+};
+
+struct HostPairPot {
+  int kind = 0;  // 0 none, 1 LJ, 2 table
+  double eps = 0, sig = 0, rc = 0, shift = 0, r0 = 0, dr = 0;
+  std::vector<double> e, f;
+};
+
+// Device-facing bonded parameter slot and CSR entry (mirrors md_kernels.hpp)
+struct HBondedParam { int kind, list, arity, pad; double p[CHEM_MAX_POT_PARAMS]; };
+struct HBondedEntry { int t0, t1, t2, meta; };
+
+struct HostTopology {
+  int64_t n = 0;
+  std::vector<int64_t> id;  // tag -> external id (ascending)
+  bool contiguous = true;
+  int64_t id0 = 0;
+  std::unordered_map<int64_t, int32_t> id2tag;
+  std::vector<int32_t> type, state, res_id, mol_id;
+  std::vector<double> mass, q;
+  std::vector<std::vector<int32_t>> graph;  // sorted adjacency (bond graph)
+  std::vector<std::vector<int32_t>> excl;   // sorted, symmetric
+  std::vector<HostList> lists;
+  int64_t n_excl_pairs = 0;
+
+  int tag_of(int64_t pid) const {
+    if (contiguous) { int64_t t = pid - id0; return (t >= 0 && t < n) ? (int)t : -1; }
+    auto it = id2tag.find(pid);
+    return it == id2tag.end() ? -1 : it->second;
+  }
+
+  static bool sorted_insert(std::vector<int32_t>& v, int32_t x) {
+    auto it = std::lower_bound(v.begin(), v.end(), x);
+    if (it != v.end() && *it == x) return false;
+    v.insert(it, x);
+    return true;
+  }
+
+  bool exclude(int32_t a, int32_t b) {
+    if (a == b) return false;
+    bool ins = sorted_insert(excl[a], b);
+    sorted_insert(excl[b], a);
+    if (ins) ++n_excl_pairs;
+    return ins;
+  }
+
+  bool list_insert(HostList& l, const int32_t* t) {
+    if (!l.seen.insert(tuple_key(t, l.arity)).second) return false;
+    l.ent.insert(l.ent.end(), t, t + l.arity);
+    return true;
+  }
+
+  void graph_add(int32_t a, int32_t b) { sorted_insert(graph[a], b); sorted_insert(graph[b], a); }
+
+  // relabel the bonded cluster containing a (a-b already linked).  Labels: res_id takes
+  // min(res_id[a],res_id[b]) (reaction.cfg: "the residue id will be transfered"), mol_id the
+  // lowest tag of the cluster.  `touched` collects tags whose labels changed.
+  void merge_cluster(int32_t a, int32_t b, bool relabel_res, std::vector<int32_t>& touched) {
+    const int32_t new_res = std::min(res_id[a], res_id[b]);
+    const int32_t new_mol = std::min(mol_id[a], mol_id[b]);
+    std::vector<int32_t> stack{a};
+    std::unordered_set<int32_t> vis{a};
+    while (!stack.empty()) {
+      int32_t p = stack.back(); stack.pop_back();
+      bool ch = false;
+      if (relabel_res && res_id[p] != new_res) { res_id[p] = new_res; ch = true; }
+      if (mol_id[p] != new_mol) { mol_id[p] = new_mol; ch = true; }
+      if (ch) touched.push_back(p);
+      for (int32_t nb : graph[p]) if (vis.insert(nb).second) stack.push_back(nb);
+    }
+  }
+
+  // place tuple t into the first list of that arity with a matching registered type tuple
+  bool spawn_tuple(int arity, const int32_t* t) {
+    for (auto& l : lists) {
+      if (l.arity != arity) continue;
+      for (auto& reg : l.registered) {
+        bool fwd = true, rev = true;
+        for (int k = 0; k < arity; ++k) {
+          if (type[t[k]] != reg[k]) fwd = false;
+          if (type[t[arity - 1 - k]] != reg[k]) rev = false;
+        }
+        if (!fwd && !rev) continue;
+        int32_t tt[4];
+        for (int k = 0; k < arity; ++k) tt[k] = fwd ? t[k] : t[arity - 1 - k];
+        if (list_insert(l, tt)) exclude(tt[0], tt[arity - 1]);
+        return true;
+      }
+    }
+    return false;
+  }
+
+  // TopologyManager reaction to freshly created bonds (canonical order = given order)
+  void on_new_bonds(const std::vector<std::pair<int32_t, int32_t>>& nb, std::vector<int32_t>& touched) {
+    for (auto& e : nb) graph_add(e.first, e.second);
+    for (auto& e : nb) merge_cluster(e.first, e.second, true, touched);
+    bool any3 = false, any4 = false;
+    for (auto& l : lists) { if (!l.registered.empty()) { any3 |= l.arity == 3; any4 |= l.arity == 4; } }
+    for (auto& e : nb) {
+      const int32_t a = e.first, b = e.second;
+      exclude(a, b);
+      if (any3) {
+        for (int32_t n1 : graph[a]) if (n1 != b) { int32_t t[3] = {n1, a, b}; spawn_tuple(3, t); }
+        for (int32_t m : graph[b]) if (m != a) { int32_t t[3] = {a, b, m}; spawn_tuple(3, t); }
+      }
+      if (any4) {
+        for (int32_t n1 : graph[a]) if (n1 != b) {
+          for (int32_t n2 : graph[n1]) if (n2 != a && n2 != b) { int32_t t[4] = {n2, n1, a, b}; spawn_tuple(4, t); }
+          for (int32_t m : graph[b]) if (m != a && m != n1) { int32_t t[4] = {n1, a, b, m}; spawn_tuple(4, t); }
+        }
+        for (int32_t m : graph[b]) if (m != a)
+          for (int32_t m2 : graph[m]) if (m2 != b && m2 != a) { int32_t t[4] = {a, b, m, m2}; spawn_tuple(4, t); }
+      }
+    }
+  }
+
+  // ---- device tables ------------------------------------------------------------------
+  // Parameter slots: one per plain list, one per (typed list, type tuple).
+  void build_bonded(std::vector<int32_t>& bstart, std::vector<HBondedEntry>& bent, std::vector<HBondedParam>& bpar) const {
+    bpar.clear();
+    std::vector<int> plain_slot(lists.size(), -1);
+    std::vector<std::map<std::array<int, 4>, int>> typed_slot(lists.size());
+    for (size_t li = 0; li < lists.size(); ++li) {
+      const HostList& l = lists[li];
+      if (!l.by_types) {
+        if (l.has_plain) {
+          HBondedParam bp{l.kind, (int)li, l.arity, 0, {0}};
+          std::copy(l.plain.begin(), l.plain.end(), bp.p);
+          plain_slot[li] = (int)bpar.size(); bpar.push_back(bp);
+        }
+      } else {
+        for (auto& kv : l.typed) {
+          HBondedParam bp{l.kind, (int)li, l.arity, 0, {0}};
+          std::copy(kv.second.begin(), kv.second.end(), bp.p);
+          typed_slot[li][kv.first] = (int)bpar.size(); bpar.push_back(bp);
+        }
+      }
+    }
+    auto slot_of = [&](size_t li, const int32_t* t) -> int {
+      const HostList& l = lists[li];
+      if (!l.by_types) return plain_slot[li];
+      std::array<int, 4> key{-1, -1, -1, -1}, rkey{-1, -1, -1, -1};
+      for (int k = 0; k < l.arity; ++k) { key[k] = type[t[k]]; rkey[l.arity - 1 - k] = type[t[k]]; }
+      auto it = typed_slot[li].find(key);
+      if (it == typed_slot[li].end()) it = typed_slot[li].find(rkey);
+      return it == typed_slot[li].end() ? -1 : it->second;
+    };
+    bstart.assign((size_t)n + 1, 0);
+    // count: pairs/triples one entry per member, quadruples two
+    for (size_t li = 0; li < lists.size(); ++li) {
+      const HostList& l = lists[li];
+      const int w = l.arity == 4 ? 2 : 1;
+      for (size_t e = 0; e + l.arity <= l.ent.size(); e += l.arity) {
+        if (slot_of(li, &l.ent[e]) < 0) continue;
+        for (int k = 0; k < l.arity; ++k) bstart[(size_t)l.ent[e + k] + 1] += w;
+      }
+    }
+    for (int64_t t = 0; t < n; ++t) bstart[t + 1] += bstart[t];
+    bent.assign((size_t)bstart[n], HBondedEntry{0, 0, 0, 0});
+    std::vector<int32_t> fill(bstart.begin(), bstart.end() - 1);
+    for (size_t li = 0; li < lists.size(); ++li) {
+      const HostList& l = lists[li];
+      for (size_t e = 0; e + l.arity <= l.ent.size(); e += l.arity) {
+        const int32_t* t = &l.ent[e];
+        const int slot = slot_of(li, t);
+        if (slot < 0) continue;
+        for (int k = 0; k < l.arity; ++k) {
+          int32_t& pos = fill[t[k]];
+          HBondedEntry be{t[0], t[1], l.arity > 2 ? t[2] : 0, slot | (k << 28)};
+          bent[pos++] = be;
+          if (l.arity == 4) bent[pos++] = HBondedEntry{t[3], 0, 0, 0};
+        }
+      }
+    }
+  }
+
+  void build_excl(std::vector<int32_t>& estart, std::vector<int32_t>& elist) const {
+    estart.assign((size_t)n + 1, 0);
+    for (int64_t t = 0; t < n; ++t) estart[t + 1] = estart[t] + (int32_t)excl[t].size();
+    elist.resize((size_t)estart[n]);
+    for (int64_t t = 0; t < n; ++t) std::copy(excl[t].begin(), excl[t].end(), elist.begin() + estart[t]);
+  }
+};
+
+}  // namespace chem

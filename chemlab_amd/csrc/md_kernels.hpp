@@ -1,0 +1,779 @@
+// md_kernels.hpp -- hand-written CDNA4 (gfx950, wave64) kernels of the reactive-MD inner loop.
+//
+// Everything is templated on the storage/compute real type R (float: production,
+// double: parity mode).  Layout in HBM (SoA of 16/32-byte vectors, cell-sorted order):
+//   x4[i] = (x, y, z, (R)type)       v4[i] = (vx, vy, vz, mass)      f4[i] = (fx, fy, fz, 0)
+//   tag[i]   : dense particle tag (rank of the external id)          img4[i]: image counters
+//   by-tag   : rtag[tag] -> i, state[tag], res_id[tag], mol_id[tag]
+//   nlist    : full neighbour list, row-major, row stride S ints, nn[i] entries used
+// No MFMA anywhere: there is no dense contraction on this path (pair sums are gathers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/chem_mi355.h"
+#include "../../include/chem_philox.h"
+
+namespace chem {
+
+template <typename R> struct Vec4T;
+template <> struct Vec4T<float> { using type = float4; };
+template <> struct Vec4T<double> { using type = double4; };
+template <typename R> using Vec4 = typename Vec4T<R>::type;
+
+template <typename R> __device__ __forceinline__ Vec4<R> mk4(R a, R b, R c, R d);
+template <> __device__ __forceinline__ float4 mk4<float>(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+template <> __device__ __forceinline__ double4 mk4<double>(double a, double b, double c, double d) { return make_double4(a, b, c, d); }
+
+__device__ __forceinline__ float rint_r(float x) { return rintf(x); }
+__device__ __forceinline__ double rint_r(double x) { return rint(x); }
+__device__ __forceinline__ float sqrt_r(float x) { return sqrtf(x); }
+__device__ __forceinline__ double sqrt_r(double x) { return sqrt(x); }
+__device__ __forceinline__ float floor_r(float x) { return floorf(x); }
+__device__ __forceinline__ double floor_r(double x) { return floor(x); }
+
+constexpr int kMaxTypes = CHEM_MAX_TYPES;
+constexpr int kWave = 64;
+
+// ---- device-resident control block (one per context) ---------------------------------
+struct DevCtl {
+  unsigned long long step_max2_bits;  // max |dx|^2 of the current step (bits of a non-negative real)
+  double acc_maxdist;                 // accumulated sqrt(max|dx|^2) since the last rebuild
+  int need_rebuild;                   // decision of the current step (read by the rebuild chain)
+  int force_rebuild;                  // host request (topology/exclusions changed)
+  int nl_overflow;                    // max neighbours seen when a row overflowed (0 = fine)
+  int stage_overflow;                 // stencil tile exceeded the LDS capacity
+  int cand_count;                     // reaction candidates appended
+  int cand_overflow;
+  int rebuild_count;
+  int skin_violation;                 // list used with acc_maxdist > skin/2 (must never happen)
+  int alive;                          // reaction resolve: pairs still undecided
+  int accepted;                       // reaction resolve: accepted events
+  long long nlist_entries;
+};
+
+template <typename R> struct Box {
+  R L[3], invL[3];
+  int nc[3];       // cells per axis (0 => brute-force list build)
+  int ncell;
+  R cell_inv[3];   // nc/L
+};
+
+// Non-bonded parameters of one type pair, pre-multiplied (gromacs_topology.py:715-721,
+// doc/topology.rst:12-14).  PairCore is the only thing the LJ fast path touches (one 16-byte
+// LDS read per pair in fp32); PairExt holds energy and table terms.
+//   kind 1: ff = r^-6 (lj1 r^-6 - lj2) r^-2,  e = r^-6 (e1 r^-6 - e2) + shift
+//   kind 2: linear table interpolation, rows (f_k, f_k+1 - f_k, e_k, e_k+1 - e_k)
+template <typename R> struct PairCore { R rc2, lj1, lj2, kind; };   // kind as R: 0 none (rc2<0), 1 LJ, 2 table
+template <typename R> struct PairExt { R e1, e2, shift, r0, inv_dr; int toff, nrow, pad; };
+
+// ---- helpers -------------------------------------------------------------------------
+template <typename R> __device__ __forceinline__ R minimg1(R d, R L, R invL) { return d - L * rint_r(d * invL); }
+
+__device__ __forceinline__ unsigned long long real_bits(float x) { return (unsigned long long)__float_as_uint(x); }
+__device__ __forceinline__ unsigned long long real_bits(double x) { return (unsigned long long)__double_as_longlong(x); }
+__device__ __forceinline__ double bits_real_f(unsigned long long b) { return (double)__uint_as_float((unsigned)b); }
+__device__ __forceinline__ double bits_real_d(unsigned long long b) { return __longlong_as_double((long long)b); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ unsigned long long lanemask_lt() {
+  int l = lane_id();
+  return l ? (~0ull >> (64 - l)) : 0ull;
+}
+
+// =======================================================================================
+// K7/K8  velocity-Verlet halves (start_simulation.py:165-167,780)
+// =======================================================================================
+template <typename R> struct LangevinP { int on; double kT, gamma, dt; uint64_t seed; uint64_t step; uint32_t phase; };
+
+template <typename R>
+__device__ __forceinline__ void langevin_force(const LangevinP<R>& lp, int tag, R mass, R vx, R vy, R vz, R& fx, R& fy, R& fz) {
+  uint32_t r[4];
+  chem_philox::langevin_draw(lp.seed, lp.step, lp.phase, (uint32_t)tag, r);
+  double m = (double)mass;
+  double pref = sqrt(24.0 * lp.kT * lp.gamma * m / lp.dt);
+  fx += (R)(-lp.gamma * m * (double)vx + pref * (chem_philox::u01(r[0]) - 0.5));
+  fy += (R)(-lp.gamma * m * (double)vy + pref * (chem_philox::u01(r[1]) - 0.5));
+  fz += (R)(-lp.gamma * m * (double)vz + pref * (chem_philox::u01(r[2]) - 0.5));
+}
+
+// mode bits: 1 = second half-kick (integrate2), 2 = first half-kick + drift (integrate1),
+// 3 = fused integrate2(step s) + integrate1(step s+1); 4 = add Langevin force to f first
+// (thermalize at aftCalcF) and, when mode has no drift..., store f_total back.
+template <typename R, int MODE, bool LANG, bool STOREF>
+__global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
+                                                    Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
+                                                    R dt, LangevinP<R> lp, DevCtl* ctl) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  R d2 = 0;
+  if (i < n) {
+    Vec4<R> v = v4[i], f = f4[i];
+    if (LANG) {
+      langevin_force<R>(lp, tag[i], v.w, v.x, v.y, v.z, f.x, f.y, f.z);
+      if (STOREF) f4[i] = f;
+    }
+    R hm = (R)0.5 * dt / v.w;
+    if (MODE & 1) { v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z; }
+    if (MODE & 2) {
+      v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z;
+      Vec4<R> x = x4[i];
+      R dx = dt * v.x, dy = dt * v.y, dz = dt * v.z;
+      x.x += dx; x.y += dy; x.z += dz;
+      x4[i] = x;
+      d2 = dx * dx + dy * dy + dz * dz;
+    }
+    v4[i] = v;
+  }
+  if (MODE & 2) {
+    // wave max via DPP-style shuffles, then one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) { R t = __shfl_xor(d2, o); d2 = t > d2 ? t : d2; }
+    if (lane_id() == 0) atomicMax(&ctl->step_max2_bits, real_bits(d2));
+  }
+}
+
+// one thread: fold the step's max displacement into the accumulated distance and decide
+template <typename R>
+__global__ void k_rebuild_decide(DevCtl* ctl, double half_skin) {
+  double m2 = sizeof(R) == 4 ? bits_real_f(ctl->step_max2_bits) : bits_real_d(ctl->step_max2_bits);
+  ctl->step_max2_bits = 0ull;
+  double acc = ctl->acc_maxdist + sqrt(m2);
+  int need = (acc > half_skin) || ctl->force_rebuild;
+  if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
+  ctl->acc_maxdist = acc;
+  ctl->need_rebuild = need;
+}
+
+// =======================================================================================
+// K1  cell binning + canonical sort (storage.decompose(), start_simulation.py:158-171)
+// =======================================================================================
+template <typename R>
+__global__ __launch_bounds__(256) void k_bin(int n, Vec4<R>* __restrict__ x4, int4* __restrict__ img4, Box<R> box,
+                                             int* __restrict__ cell_cnt, int* __restrict__ cell_of,
+                                             int* __restrict__ slot_of, const DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Vec4<R> x = x4[i];
+  int4 im = img4[i];
+  R* p = &x.x; int* ip = &im.x;
+  int c[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    R s = floor_r(p[d] * box.invL[d]);
+    if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
+    if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
+    if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
+    int cc = (int)(p[d] * box.cell_inv[d]);
+    int ncd = box.nc[d] > 0 ? box.nc[d] : 1;
+    cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
+    c[d] = cc;
+  }
+  x4[i] = x; img4[i] = im;
+  int cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
+  cell_of[i] = cid;
+  slot_of[i] = atomicAdd(&cell_cnt[cid], 1);
+}
+
+// single-block exclusive scan of cell counts -> cell_start[0..ncell]; zeroes cell_cnt for next time
+__global__ __launch_bounds__(1024) void k_scan_cells(int ncell, int* __restrict__ cell_cnt, int* __restrict__ cell_start,
+                                                     const DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ncell; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < ncell ? cell_cnt[i] : 0;
+    if (i < ncell) cell_cnt[i] = 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane_id() >= o) incl += t; }
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 63) wsum[w] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < w; ++k) woff += wsum[k];
+    int tot = 0;
+    for (int k = 0; k < 16; ++k) tot += wsum[k];
+    int c0 = carry;
+    if (i < ncell) cell_start[i] = c0 + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry = c0 + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cell_start[ncell] = carry;
+}
+
+__global__ __launch_bounds__(256) void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of,
+                                               const int* __restrict__ cell_start, int* __restrict__ perm, const DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) perm[cell_start[cell_of[i]] + slot_of[i]] = i;
+}
+
+// canonical order inside a cell: ascending tag (makes the whole pipeline run-to-run deterministic)
+__global__ __launch_bounds__(256) void k_sort_cells(int ncell, const int* __restrict__ cell_start, int* __restrict__ perm,
+                                                    const int* __restrict__ tag, const DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncell) return;
+  int s = cell_start[c], e = cell_start[c + 1];
+  for (int a = s + 1; a < e; ++a) {
+    int pa = perm[a], ta = tag[pa], b = a - 1;
+    while (b >= s) { int pb = perm[b]; if (tag[pb] <= ta) break; perm[b + 1] = pb; --b; }
+    perm[b + 1] = pa;
+  }
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_gather(int n, const int* __restrict__ perm, const Vec4<R>* __restrict__ x4,
+                                                const Vec4<R>* __restrict__ v4,
+                                                const int* __restrict__ tag, const int4* __restrict__ img4,
+                                                Vec4<R>* __restrict__ x4o, Vec4<R>* __restrict__ v4o,
+                                                int* __restrict__ tago, int4* __restrict__ img4o, const DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  int i = perm[k];
+  x4o[k] = x4[i]; v4o[k] = v4[i]; tago[k] = tag[i]; img4o[k] = img4[i];
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_copyback(int n, const Vec4<R>* __restrict__ x4o, const Vec4<R>* __restrict__ v4o,
+                                                  const int* __restrict__ tago,
+                                                  const int4* __restrict__ img4o, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
+                                                  int* __restrict__ tag, int4* __restrict__ img4,
+                                                  int* __restrict__ rtag, const DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  x4[k] = x4o[k]; v4[k] = v4o[k]; img4[k] = img4o[k];
+  int t = tago[k]; tag[k] = t; rtag[t] = k;
+}
+
+// =======================================================================================
+// K2  Verlet neighbour-list build (VerletList(system, cutoff, exclusionlist),
+//     start_simulation.py:193-197).  One workgroup per home cell: the 27-cell stencil is
+//     staged in LDS with the periodic shift applied, each wave then owns home particles and
+//     tests 64 staged candidates per instruction; __ballot + popcount compacts the hits into
+//     the particle's row with coalesced stores.
+// =======================================================================================
+template <typename R, int CAP>
+__global__ __launch_bounds__(256) void k_nlist_cells(int n, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+                                                     const int* __restrict__ cell_start, Box<R> box, R rl2,
+                                                     const int* __restrict__ excl_start, const int* __restrict__ excl_list,
+                                                     int has_excl, int* __restrict__ nlist, int* __restrict__ nn, int S,
+                                                     DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  __shared__ Vec4<R> sx[CAP];
+  __shared__ int sidx[CAP];
+  __shared__ int seg_start[27], seg_cnt[27], seg_off[28];
+  __shared__ R seg_shift[27][3];
+  const int c = blockIdx.x;
+  const int nx = box.nc[0], ny = box.nc[1], nz = box.nc[2];
+  const int cx = c % nx, cy = (c / nx) % ny, cz = c / (nx * ny);
+  if (threadIdx.x < 27) {
+    int k = threadIdx.x;
+    int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+    int ox = cx + dx, oy = cy + dy, oz = cz + dz;
+    R sh[3] = {0, 0, 0};
+    if (ox < 0) { ox += nx; sh[0] = -box.L[0]; } else if (ox >= nx) { ox -= nx; sh[0] = box.L[0]; }
+    if (oy < 0) { oy += ny; sh[1] = -box.L[1]; } else if (oy >= ny) { oy -= ny; sh[1] = box.L[1]; }
+    if (oz < 0) { oz += nz; sh[2] = -box.L[2]; } else if (oz >= nz) { oz -= nz; sh[2] = box.L[2]; }
+    int oc = (oz * ny + oy) * nx + ox;
+    seg_start[k] = cell_start[oc];
+    seg_cnt[k] = cell_start[oc + 1] - cell_start[oc];
+    seg_shift[k][0] = sh[0]; seg_shift[k][1] = sh[1]; seg_shift[k][2] = sh[2];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int o = 0;
+    for (int k = 0; k < 27; ++k) { seg_off[k] = o; o += seg_cnt[k]; }
+    seg_off[27] = o;
+    if (o > CAP) atomicMax(&ctl->stage_overflow, o);
+  }
+  __syncthreads();
+  const int total = min(seg_off[27], CAP);
+  // stage: one wave per segment round-robin, coalesced 16/32-byte loads
+  const int w = threadIdx.x >> 6, l = lane_id();
+  for (int k = w; k < 27; k += 4) {
+    const int s0 = seg_start[k], cnt = seg_cnt[k], o0 = seg_off[k];
+    const R sh0 = seg_shift[k][0], sh1 = seg_shift[k][1], sh2 = seg_shift[k][2];
+    for (int t = l; t < cnt; t += 64) {
+      int dst = o0 + t;
+      if (dst < CAP) {
+        Vec4<R> p = x4[s0 + t];
+        p.x += sh0; p.y += sh1; p.z += sh2;
+        sx[dst] = p; sidx[dst] = s0 + t;
+      }
+    }
+  }
+  __syncthreads();
+  const int hs = cell_start[c], he = cell_start[c + 1];
+  for (int p = hs + w; p < he; p += 4) {
+    const Vec4<R> xi = x4[p];
+    int e0 = 0, e1 = 0;
+    if (has_excl) { int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
+    int cnt = 0;
+    int* row = nlist + (size_t)p * S;
+    for (int s0 = 0; s0 < total; s0 += 64) {
+      const int s = s0 + l;
+      bool ok = s < total;
+      int j = -1;
+      if (ok) {
+        const Vec4<R> xj = sx[s];
+        j = sidx[s];
+        const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+        const R r2 = dx * dx + dy * dy + dz * dz;
+        ok = (r2 <= rl2) && (j != p);
+        if (ok && e1 > e0) {
+          const int tj = tag[j];
+          for (int e = e0; e < e1; ++e) if (excl_list[e] == tj) { ok = false; break; }
+        }
+      }
+      const unsigned long long m = __ballot(ok);
+      if (ok) {
+        const int pos = cnt + __popcll(m & lanemask_lt());
+        if (pos < S) row[pos] = j;
+      }
+      cnt += __popcll(m);
+    }
+    if (l == 0) {
+      nn[p] = cnt < S ? cnt : S;
+      if (cnt > S) atomicMax(&ctl->nl_overflow, cnt);
+    }
+  }
+}
+
+// brute-force variant for boxes with fewer than 3 cells per axis (tiny test systems):
+// one wave per particle, all other particles are candidates, minimum image.
+template <typename R>
+__global__ __launch_bounds__(256) void k_nlist_brute(int n, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+                                                     Box<R> box, R rl2, const int* __restrict__ excl_start,
+                                                     const int* __restrict__ excl_list, int has_excl,
+                                                     int* __restrict__ nlist, int* __restrict__ nn, int S, DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  const int l = lane_id();
+  const Vec4<R> xi = x4[p];
+  int e0 = 0, e1 = 0;
+  if (has_excl) { int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
+  int cnt = 0;
+  int* row = nlist + (size_t)p * S;
+  for (int s0 = 0; s0 < n; s0 += 64) {
+    const int j = s0 + l;
+    bool ok = j < n && j != p;
+    if (ok) {
+      const Vec4<R> xj = x4[j];
+      const R dx = minimg1<R>(xi.x - xj.x, box.L[0], box.invL[0]);
+      const R dy = minimg1<R>(xi.y - xj.y, box.L[1], box.invL[1]);
+      const R dz = minimg1<R>(xi.z - xj.z, box.L[2], box.invL[2]);
+      ok = dx * dx + dy * dy + dz * dz <= rl2;
+      if (ok && e1 > e0) {
+        const int tj = tag[j];
+        for (int e = e0; e < e1; ++e) if (excl_list[e] == tj) { ok = false; break; }
+      }
+    }
+    const unsigned long long m = __ballot(ok);
+    if (ok) { const int pos = cnt + __popcll(m & lanemask_lt()); if (pos < S) row[pos] = j; }
+    cnt += __popcll(m);
+  }
+  if (l == 0) { nn[p] = cnt < S ? cnt : S; if (cnt > S) atomicMax(&ctl->nl_overflow, cnt); }
+}
+
+// =======================================================================================
+// K3  non-bonded pair forces over the Verlet list (VerletListLennardJones /
+//     VerletListTabulated, gromacs_topology.py:511-512,696-721).  TPP lanes cooperate on one
+//     particle: lane t handles neighbours t, t+TPP, ...; partial forces are combined with a
+//     segmented xor-shuffle reduction.  Full list => no atomics, deterministic sums.
+// =======================================================================================
+template <typename R, bool ENERGY>
+__device__ __forceinline__ void pair_term(const PairCore<R> pc, const PairExt<R>* __restrict__ pext, int pidx,
+                                          const Vec4<R>* __restrict__ tab, R r2, R dx, R dy, R dz,
+                                          R& fx, R& fy, R& fz, double& e_lj, double& e_tab, double& vir) {
+  if (r2 <= pc.rc2) {
+    if (pc.kind == (R)1) {
+      const R r2i = (R)1 / r2, r6i = r2i * r2i * r2i;
+      const R ff = r6i * (pc.lj1 * r6i - pc.lj2) * r2i;
+      fx += ff * dx; fy += ff * dy; fz += ff * dz;
+      if (ENERGY) { const PairExt<R> px = pext[pidx]; e_lj += (double)(r6i * (px.e1 * r6i - px.e2) + px.shift); vir += (double)(ff * r2); }
+    } else {
+      const PairExt<R> px = pext[pidx];
+      const R r = sqrt_r(r2);
+      R t = (r - px.r0) * px.inv_dr;
+      const R tmax = (R)(px.nrow - 1);
+      t = t < (R)0 ? (R)0 : (t > tmax ? tmax : t);
+      int k = (int)t;
+      if (k > px.nrow - 2) k = px.nrow - 2;
+      const R wgt = t - (R)k;
+      const Vec4<R> row = tab[px.toff + k];  // (f_k, df_k, e_k, de_k)
+      const R ff = (row.x + wgt * row.y) / r;
+      fx += ff * dx; fy += ff * dy; fz += ff * dz;
+      if (ENERGY) { e_tab += (double)(row.z + wgt * row.w); vir += (double)(ff * r2); }
+    }
+  }
+}
+
+template <typename R, int TPP, bool ENERGY>
+__global__ __launch_bounds__(256) void k_pair_force(int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
+                                                    const int* __restrict__ nlist, const int* __restrict__ nn, int S,
+                                                    Box<R> box, const PairCore<R>* __restrict__ pcore,
+                                                    const PairExt<R>* __restrict__ pext, int ntypes,
+                                                    const Vec4<R>* __restrict__ tab, double* __restrict__ eout,
+                                                    double half_skin, DevCtl* ctl) {
+  __shared__ PairCore<R> spc[kMaxTypes * kMaxTypes];
+  for (int k = threadIdx.x; k < ntypes * ntypes; k += blockDim.x) spc[k] = pcore[k];
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x == 0 && ctl->acc_maxdist > half_skin) ctl->skin_violation = 1;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid / TPP, sub = gid % TPP;
+  R fx = 0, fy = 0, fz = 0;
+  double e_lj = 0, e_tab = 0, vir = 0;
+  if (i < n) {
+    const Vec4<R> xi = x4[i];
+    const int ti = (int)xi.w;
+    const int cnt = nn[i];
+    const int* row = nlist + (size_t)i * S;
+    const int pbase = ti * ntypes;
+    for (int k = sub; k < cnt; k += TPP) {
+      const int j = row[k];
+      const Vec4<R> xj = x4[j];
+      const R dx = minimg1<R>(xi.x - xj.x, box.L[0], box.invL[0]);
+      const R dy = minimg1<R>(xi.y - xj.y, box.L[1], box.invL[1]);
+      const R dz = minimg1<R>(xi.z - xj.z, box.L[2], box.invL[2]);
+      const R r2 = dx * dx + dy * dy + dz * dz;
+      const int pidx = pbase + (int)xj.w;
+      pair_term<R, ENERGY>(spc[pidx], pext, pidx, tab, r2, dx, dy, dz, fx, fy, fz, e_lj, e_tab, vir);
+    }
+  }
+  if (TPP > 1) {
+#pragma unroll
+    for (int o = TPP / 2; o > 0; o >>= 1) {
+      fx += __shfl_xor(fx, o); fy += __shfl_xor(fy, o); fz += __shfl_xor(fz, o);
+    }
+  }
+  if (i < n && sub == 0) f4[i] = mk4<R>(fx, fy, fz, (R)0);
+  if (ENERGY) {
+    // full list: every pair is visited from both ends -> half weights
+    __shared__ double red[3][4];
+    for (int o = 32; o > 0; o >>= 1) { e_lj += __shfl_xor(e_lj, o); e_tab += __shfl_xor(e_tab, o); vir += __shfl_xor(vir, o); }
+    if (lane_id() == 0) { red[0][threadIdx.x >> 6] = e_lj; red[1][threadIdx.x >> 6] = e_tab; red[2][threadIdx.x >> 6] = vir; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0, b = 0, c = 0;
+      for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += red[0][k]; b += red[1][k]; c += red[2][k]; }
+      eout[3 * blockIdx.x + 0] = 0.5 * a; eout[3 * blockIdx.x + 1] = 0.5 * b; eout[3 * blockIdx.x + 2] = 0.5 * c;
+    }
+  }
+}
+
+// =======================================================================================
+// K4-K6  bonded forces (FixedPairList/TripleList/QuadrupleList interactions,
+//     gromacs_topology.py:949-961,1086-1096,1206-1224).  Per-particle CSR (by tag): every
+//     member of a tuple evaluates the term and keeps its own force -> no atomics,
+//     deterministic.  Geometry in fp64 in both precision modes.
+// =======================================================================================
+struct BondedEntry { int t0, t1, t2, meta; };   // tuple tags in order (self included); meta = slot | mypos<<28; quadruples use a 2nd entry for t3
+struct BondedParam { int kind, list, arity, pad; double p[CHEM_MAX_POT_PARAMS]; };
+
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ double dot3(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ D3 cross3(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+struct BoxD { double L[3], invL[3]; };
+__device__ __forceinline__ D3 minimgD(const BoxD& b, D3 d) {
+  return {d.x - b.L[0] * rint(d.x * b.invL[0]), d.y - b.L[1] * rint(d.y * b.invL[1]), d.z - b.L[2] * rint(d.z * b.invL[2])};
+}
+template <typename R> __device__ __forceinline__ D3 posD(const Vec4<R>& v) { return {(double)v.x, (double)v.y, (double)v.z}; }
+
+template <typename R, bool ENERGY>
+__global__ __launch_bounds__(256) void k_bonded(int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
+                                                const int* __restrict__ tag, const int* __restrict__ rtag,
+                                                const int* __restrict__ bstart, const BondedEntry* __restrict__ bent,
+                                                const BondedParam* __restrict__ bpar, BoxD box, double* __restrict__ elist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int tg = tag[i];
+  const int e0 = bstart[tg], e1 = bstart[tg + 1];
+  if (e0 == e1) return;
+  D3 f = {0, 0, 0};
+  for (int e = e0; e < e1; ++e) {
+    const BondedEntry be = bent[e];
+    const int slot = be.meta & 0x0fffffff, me = (be.meta >> 28) & 3;
+    const BondedParam bp = bpar[slot];
+    const double* p = bp.p;
+    double u = 0;
+    if (bp.arity == 2) {
+      // tuple (t0,t1); r_ij = x_t0 - x_t1
+      const D3 x0 = posD<R>(x4[rtag[be.t0]]), x1 = posD<R>(x4[rtag[be.t1]]);
+      const D3 d = minimgD(box, x0 - x1);
+      const double r = sqrt(dot3(d, d));
+      double ff = 0;
+      if (bp.kind == CHEM_POT_HARMONIC) { const double dr = r - p[1]; u = p[0] * dr * dr; ff = -2.0 * p[0] * dr / r; }
+      else if (bp.kind == CHEM_POT_FENE) { const double dr = r - p[1], q = dr / p[2], den = 1.0 - q * q; u = -0.5 * p[0] * p[2] * p[2] * log(den); ff = -p[0] * dr / den / r; }
+      const double sgn = me == 0 ? 1.0 : -1.0;
+      f = f + (sgn * ff) * d;
+    } else if (bp.arity == 3) {
+      const D3 x0 = posD<R>(x4[rtag[be.t0]]), x1 = posD<R>(x4[rtag[be.t1]]), x2 = posD<R>(x4[rtag[be.t2]]);
+      const D3 r1 = minimgD(box, x0 - x1), r2 = minimgD(box, x2 - x1);
+      const double n1 = sqrt(dot3(r1, r1)), n2 = sqrt(dot3(r2, r2));
+      double c = dot3(r1, r2) / (n1 * n2);
+      c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+      const double th = acos(c);
+      double s = sqrt(1.0 - c * c);
+      if (s < 1e-9) s = 1e-9;
+      double dU = 0;
+      if (bp.kind == CHEM_POT_ANG_HARMONIC) { const double d = th - p[1]; u = p[0] * d * d; dU = 2.0 * p[0] * d; }
+      else if (bp.kind == CHEM_POT_ANG_COSINE) { u = p[0] * (1.0 + cos(th - p[1])); dU = -p[0] * sin(th - p[1]); }
+      const double a = dU / s;
+      const D3 fi = a * ((1.0 / (n1 * n2)) * r2 - (c / (n1 * n1)) * r1);
+      const D3 fk = a * ((1.0 / (n1 * n2)) * r1 - (c / (n2 * n2)) * r2);
+      if (me == 0) f = f + fi; else if (me == 2) f = f + fk; else f = f - (fi + fk);
+    } else {
+      const BondedEntry be2 = bent[e + 1];  // quadruples occupy two consecutive entries: (t0,t1,t2,meta),(t3,-,-,-)
+      const D3 x0 = posD<R>(x4[rtag[be.t0]]), x1 = posD<R>(x4[rtag[be.t1]]), x2 = posD<R>(x4[rtag[be.t2]]), x3 = posD<R>(x4[rtag[be2.t0]]);
+      ++e;
+      const D3 b1 = minimgD(box, x1 - x0), b2 = minimgD(box, x2 - x1), b3 = minimgD(box, x3 - x2);
+      const D3 m = cross3(b1, b2), nn = cross3(b2, b3);
+      const double m2 = dot3(m, m), n2 = dot3(nn, nn), lb2 = dot3(b2, b2), lb = sqrt(lb2);
+      if (m2 < 1e-30 || n2 < 1e-30) continue;
+      const double phi = atan2(lb * dot3(b1, nn), dot3(m, nn));
+      double dU = 0;
+      if (bp.kind == CHEM_POT_DIH_NCOS) { u = p[0] * (1.0 + cos(p[2] * phi - p[1])); dU = -p[0] * p[2] * sin(p[2] * phi - p[1]); }
+      else if (bp.kind == CHEM_POT_DIH_RB) {
+        const double psi = phi - M_PI, cp = cos(psi), sp = sin(psi);
+        double pw = 1.0, dsum = 0;
+        for (int k = 0; k < 6; ++k) { u += p[k] * pw; if (k < 5) dsum += (k + 1) * p[k + 1] * pw; pw *= cp; }
+        dU = -sp * dsum;
+      }
+      const D3 g1 = (-lb / m2) * m, g4 = (lb / n2) * nn;
+      const double s12 = dot3(b1, b2) / lb2, s32 = dot3(b3, b2) / lb2;
+      D3 g;
+      if (me == 0) g = g1;
+      else if (me == 3) g = g4;
+      else if (me == 1) g = (-1.0 - s12) * g1 + s32 * g4;
+      else g = (-1.0 - s32) * g4 + s12 * g1;
+      f = f - dU * g;
+    }
+    if (ENERGY && me == 0) atomicAdd(&elist[bp.list], u);
+  }
+  Vec4<R> fo = f4[i];
+  fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;
+  f4[i] = fo;
+}
+
+// =======================================================================================
+// K11 observables (analysis.Temperature/KineticEnergy, start_simulation.py:453-493)
+// =======================================================================================
+template <typename R>
+__global__ __launch_bounds__(256) void k_kinetic(int n, const Vec4<R>* __restrict__ v4, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  double ek = 0, px = 0, py = 0, pz = 0;
+  if (i < n) {
+    const Vec4<R> v = v4[i];
+    const double m = (double)v.w, vx = (double)v.x, vy = (double)v.y, vz = (double)v.z;
+    ek = 0.5 * m * (vx * vx + vy * vy + vz * vz); px = m * vx; py = m * vy; pz = m * vz;
+  }
+  __shared__ double red[4][4];
+  for (int o = 32; o > 0; o >>= 1) { ek += __shfl_xor(ek, o); px += __shfl_xor(px, o); py += __shfl_xor(py, o); pz += __shfl_xor(pz, o); }
+  if (lane_id() == 0) { int w = threadIdx.x >> 6; red[0][w] = ek; red[1][w] = px; red[2][w] = py; red[3][w] = pz; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double s = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[threadIdx.x][k];
+    out[4 * blockIdx.x + threadIdx.x] = s;
+  }
+}
+
+// =======================================================================================
+// K9/K10  reaction scan + resolve (integrator.ChemicalReaction / Reaction,
+//     reaction_setup.py:71-165,416-427)
+// =======================================================================================
+struct ReactionDev {
+  int type_1, type_2, delta_1, delta_2;
+  int min1, max1, min2, max2;
+  int intramolecular, intraresidual, active, pad;
+  double cut2, mincut2, prob;
+};
+struct ReactSet { int n; uint64_t seed; uint64_t step; int nearest; ReactionDev r[CHEM_MAX_REACTIONS]; };
+
+struct Candidate { int a, b, r; unsigned int h; double d2; };  // a: role type_1, b: role type_2 (tags)
+
+// Traverses the Verlet list once (pairs with tag_i < tag_j), applies the type/state/res_id
+// filters, evaluates the distance criterion in fp64 without FMA contraction (bit-comparable
+// with the CPU oracle) and appends the hits with one atomic per wave (ballot compaction).
+template <typename R>
+__global__ __launch_bounds__(256) void k_react_scan(int n, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+                                                    const int* __restrict__ nlist, const int* __restrict__ nn, int S,
+                                                    const int* __restrict__ state, const int* __restrict__ res_id,
+                                                    const int* __restrict__ mol_id, BoxD box, const ReactSet* __restrict__ rs_g,
+                                                    Candidate* __restrict__ cand, int cand_cap, DevCtl* ctl) {
+  __shared__ ReactSet rs;
+  {
+    const int* src = reinterpret_cast<const int*>(rs_g);
+    int* dst = reinterpret_cast<int*>(&rs);
+    for (int k = threadIdx.x; k < (int)(sizeof(ReactSet) / 4); k += blockDim.x) dst[k] = src[k];
+  }
+  __syncthreads();
+  // 8 lanes per particle row
+  constexpr int TPP = 8;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = gid / TPP, sub = gid % TPP;
+  int cnt = 0, ti = 0, si = 0, tgi = 0, ri = 0, mi = 0;
+  Vec4<R> xi = mk4<R>(0, 0, 0, 0);
+  const int* row = nullptr;
+  if (i < n) {
+    xi = x4[i]; ti = (int)xi.w; tgi = tag[i]; si = state[tgi]; ri = res_id[tgi]; mi = mol_id[tgi];
+    cnt = nn[i]; row = nlist + (size_t)i * S;
+    // quick reject: particle cannot take part in any active reaction
+    bool any = false;
+    for (int q = 0; q < rs.n; ++q) {
+      const ReactionDev& R_ = rs.r[q];
+      if (!R_.active) continue;
+      any |= (ti == R_.type_1 && si >= R_.min1 && si < R_.max1) || (ti == R_.type_2 && si >= R_.min2 && si < R_.max2);
+    }
+    if (!any) cnt = 0;
+  }
+  // uniform trip count inside a wave so that __ballot is convergent
+  int maxcnt = cnt;
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(maxcnt, o); maxcnt = t > maxcnt ? t : maxcnt; }
+  for (int k0 = 0; k0 < maxcnt; k0 += TPP) {
+    const int k = k0 + sub;
+    int j = -1, tj = 0, sj = 0, tgj = 0, rj = 0, mj = 0;
+    bool live = k < cnt;
+    Vec4<R> xj = xi;
+    if (live) {
+      j = row[k]; tgj = tag[j];
+      live = tgi < tgj;
+      if (live) { xj = x4[j]; tj = (int)xj.w; sj = state[tgj]; rj = res_id[tgj]; mj = mol_id[tgj]; }
+    }
+    double d2 = 0;
+    if (__any(live)) {
+      if (live) {
+        D3 d = minimgD(box, posD<R>(xi) - posD<R>(xj));
+        d2 = __dadd_rn(__dadd_rn(__dmul_rn(d.x, d.x), __dmul_rn(d.y, d.y)), __dmul_rn(d.z, d.z));
+      }
+      for (int q = 0; q < rs.n; ++q) {
+        const ReactionDev& R_ = rs.r[q];
+        bool hit = false; int a = 0, b = 0; unsigned int h = 0;
+        if (live && R_.active) {
+          const bool fwd = ti == R_.type_1 && si >= R_.min1 && si < R_.max1 && tj == R_.type_2 && sj >= R_.min2 && sj < R_.max2;
+          const bool rev = tj == R_.type_1 && sj >= R_.min1 && sj < R_.max1 && ti == R_.type_2 && si >= R_.min2 && si < R_.max2;
+          if (fwd || rev) {
+            hit = true;
+            if (fwd) { a = tgi; b = tgj; } else { a = tgj; b = tgi; }   // tgi < tgj: forward role assignment wins
+            if (!R_.intraresidual && ri == rj) hit = false;
+            if (!R_.intramolecular && mi == mj) hit = false;
+            if (!(d2 >= R_.mincut2 && d2 < R_.cut2)) hit = false;
+            if (hit) {
+              uint32_t rr[4];
+              chem_philox::reaction_draw(rs.seed, rs.step, (uint32_t)tgi, (uint32_t)tgj, (uint32_t)q, rr);
+              if (R_.prob < 1.0 && !(chem_philox::u01(rr[0]) < R_.prob)) hit = false;
+              h = rr[1];
+            }
+          }
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+          int base = 0;
+          if (lane_id() == 0) base = atomicAdd(&ctl->cand_count, __popcll(m));
+          base = __shfl(base, 0);
+          if (hit) {
+            const int pos = base + __popcll(m & lanemask_lt());
+            if (pos < cand_cap) cand[pos] = Candidate{a, b, q, h, d2};
+            else ctl->cand_overflow = 1;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- resolve: UniqueA, UniqueB, one-event-per-particle (parallel greedy) -------------
+__device__ __forceinline__ unsigned long long cand_key1(const Candidate& c, int nearest) {
+  return nearest ? (unsigned long long)__double_as_longlong(c.d2) : (unsigned long long)c.h;
+}
+
+// pass 1 of a segmented arg-min: best1[p] = min key1; side 0: p = a, side 1: p = b
+__global__ void k_res_min1(int nc, const Candidate* __restrict__ c, const int* __restrict__ alive, int side, int nearest,
+                           unsigned long long* __restrict__ best1) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nc || !alive[k]) return;
+  atomicMin(&best1[side ? c[k].b : c[k].a], cand_key1(c[k], nearest));
+}
+// pass 2: tie-break on (partner tag, reaction)
+__global__ void k_res_min2(int nc, const Candidate* __restrict__ c, const int* __restrict__ alive, int side, int nearest,
+                           const unsigned long long* __restrict__ best1, unsigned long long* __restrict__ best2) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nc || !alive[k]) return;
+  const int p = side ? c[k].b : c[k].a, o = side ? c[k].a : c[k].b;
+  if (cand_key1(c[k], nearest) == best1[p]) atomicMin(&best2[p], ((unsigned long long)(unsigned)o << 8) | (unsigned)c[k].r);
+}
+__global__ void k_res_keep(int nc, const Candidate* __restrict__ c, int* __restrict__ alive, int side, int nearest,
+                           const unsigned long long* __restrict__ best1, const unsigned long long* __restrict__ best2) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nc || !alive[k]) return;
+  const int p = side ? c[k].b : c[k].a, o = side ? c[k].a : c[k].b;
+  const bool keep = cand_key1(c[k], nearest) == best1[p] && ((((unsigned long long)(unsigned)o << 8) | (unsigned)c[k].r) == best2[p]);
+  if (!keep) alive[k] = 0;
+}
+// after UniqueA+UniqueB every particle is 'a' of at most one and 'b' of at most one survivor
+__global__ void k_res_index(int nc, const Candidate* __restrict__ c, const int* __restrict__ alive, int* __restrict__ asA,
+                            int* __restrict__ asB) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nc || !alive[k]) return;
+  asA[c[k].a] = k; asB[c[k].b] = k;
+}
+__device__ __forceinline__ bool cand_less(const Candidate& p, const Candidate& q, int nearest) {
+  const unsigned long long kp = cand_key1(p, nearest), kq = cand_key1(q, nearest);
+  return kp != kq ? kp < kq : p.a < q.a;
+}
+// one round of priority greedy matching: status 1 alive, 2 accepted, 0 dead
+__global__ void k_res_round(int nc, const Candidate* __restrict__ c, const int* __restrict__ st_in, int* __restrict__ st_out,
+                            const int* __restrict__ asA, const int* __restrict__ asB, int nearest, DevCtl* ctl) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nc) return;
+  int s = st_in[k];
+  if (s == 1) {
+    // neighbours: pairs sharing a particle with k
+    int nb[4] = {asB[c[k].a], asA[c[k].b], asA[c[k].a], asB[c[k].b]};
+    bool ismin = true, dead = false;
+    for (int q = 0; q < 4; ++q) {
+      const int o = nb[q];
+      if (o < 0 || o == k) continue;
+      const int so = st_in[o];
+      if (so == 2) dead = true;
+      else if (so == 1 && cand_less(c[o], c[k], nearest)) ismin = false;
+    }
+    if (dead) s = 0; else if (ismin) { s = 2; atomicAdd(&ctl->accepted, 1); } else atomicAdd(&ctl->alive, 1);
+  }
+  st_out[k] = s;
+}
+
+// apply accepted events: state/type/mass on the device arrays, emit compact event records
+struct ReactApply { int delta_1, delta_2, new_type_1, new_type_2; double new_mass_1, new_mass_2; };
+struct ReactApplySet { ReactApply r[CHEM_MAX_REACTIONS]; };
+template <typename R>
+__global__ void k_react_apply(int nc, const Candidate* __restrict__ c, const int* __restrict__ st, ReactApplySet ras,
+                              int* __restrict__ state, const int* __restrict__ rtag, Vec4<R>* __restrict__ x4,
+                              Vec4<R>* __restrict__ v4, Candidate* __restrict__ out, int* __restrict__ out_count) {
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nc || st[k] != 2) return;
+  const Candidate cd = c[k];
+  const ReactApply ra = ras.r[cd.r];
+  state[cd.a] += ra.delta_1; state[cd.b] += ra.delta_2;
+  if (ra.new_type_1 >= 0) { int i = rtag[cd.a]; x4[i].w = (R)ra.new_type_1; v4[i].w = (R)ra.new_mass_1; }
+  if (ra.new_type_2 >= 0) { int i = rtag[cd.b]; x4[i].w = (R)ra.new_type_2; v4[i].w = (R)ra.new_mass_2; }
+  out[atomicAdd(out_count, 1)] = cd;
+}
+
+template <typename T> __global__ void k_fill(T* p, T v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+}  // namespace chem

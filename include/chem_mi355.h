@@ -1,0 +1,241 @@
+/*
+ * chem_mi355.h -- C ABI of libchem_mi355.so, the MI355X-native reactive-MD inner loop
+ * that replaces the modified-ESPResSo++ back end ChemLab drives.
+ *
+ * The reference (cgchemlab/chemlab) has no C ABI: its hot path is reached through
+ * Boost.Python `espressopp.*` objects.  Every entry point below therefore cites the
+ * ChemLab call site (file:line under /root/reference) whose espressopp call it replaces.
+ * INTEGRATION.md shows the py3 `espressopp`-shaped shim (ctypes) a maintainer binds
+ * on top of these symbols.
+ *
+ * Conventions
+ *  - every function returns 0 (or a count >= 0) on success and a negative CHEM_E* code on
+ *    failure; the message is available from chem_last_error(ctx);
+ *  - the caller owns every input buffer; it is copied during the call;
+ *  - the context owns all device memory; outputs go to caller-allocated buffers with a
+ *    capacity, the return value is the element count (CHEM_ENOSPC if cap is too small);
+ *  - a context is bound to one GPU and is not thread-safe; multi-GPU = one context per
+ *    rank (one process per GPU), joined with chem_comm_init();
+ *  - there is NO CPU fall-back behind these symbols: without a gfx950 device
+ *    chem_create() fails.
+ */
+#ifndef CHEM_MI355_H
+#define CHEM_MI355_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CHEM_ABI_VERSION 1
+
+/* error codes */
+#define CHEM_OK        0
+#define CHEM_EINVAL   -1   /* bad argument */
+#define CHEM_ENOSPC   -2   /* output capacity too small / internal capacity exceeded */
+#define CHEM_EDEVICE  -3   /* HIP error or no usable device */
+#define CHEM_ESTATE   -4   /* call sequence error (e.g. run before particles) */
+#define CHEM_ENOTIMPL -5   /* feature outside the hot-path scope */
+#define CHEM_ECOMM    -6   /* RCCL error */
+
+/* arithmetic precision of the device path (chem_create) */
+#define CHEM_PREC_F32 32   /* fp32 positions/velocities/forces, fp64 bonded + reaction distance */
+#define CHEM_PREC_F64 64   /* everything fp64 (parity mode)                                    */
+
+/* bonded potential kinds (chem_list_create).  Parameter vectors `p` for chem_list_set_params:
+ *   HARMONIC        K, r0                 U = K (r-r0)^2            gromacs_topology.py:918,949-961
+ *   FENE            K, r0, rMax           U = -K/2 rMax^2 ln(1-((r-r0)/rMax)^2)      :926-931
+ *   ANG_HARMONIC    K, theta0[rad]        U = K (theta-theta0)^2                    :1073,1086
+ *   ANG_COSINE      K, theta0[rad]        U = K (1+cos(theta-theta0))               :1082
+ *   DIH_NCOS        K, phi0[rad], n       U = K (1+cos(n phi - phi0))               :1185-1190
+ *   DIH_RB          C0..C5                U = sum_n C_n cos^n(phi-pi)               :1192-1198
+ */
+#define CHEM_POT_HARMONIC      1
+#define CHEM_POT_FENE          2
+#define CHEM_POT_ANG_HARMONIC 10
+#define CHEM_POT_ANG_COSINE   11
+#define CHEM_POT_DIH_NCOS     20
+#define CHEM_POT_DIH_RB       21
+#define CHEM_MAX_POT_PARAMS    6
+#define CHEM_MAX_LISTS        32
+#define CHEM_MAX_TYPES        16
+#define CHEM_MAX_REACTIONS    16
+
+/* selectors for chem_get_state; all outputs are in ascending particle-id order */
+#define CHEM_STATE_POS     1   /* double[n*3], folded into the box                 */
+#define CHEM_STATE_VEL     2   /* double[n*3]                                      */
+#define CHEM_STATE_FORCE   3   /* double[n*3], forces of the last evaluation       */
+#define CHEM_STATE_TYPE    4   /* int32[n]                                         */
+#define CHEM_STATE_STATE   5   /* int32[n]  chemical state                         */
+#define CHEM_STATE_RESID   6   /* int32[n]                                         */
+#define CHEM_STATE_MASS    7   /* double[n]                                        */
+#define CHEM_STATE_ID      8   /* int64[n]                                         */
+#define CHEM_STATE_IMAGE   9   /* int32[n*3] periodic image counters               */
+#define CHEM_STATE_MOLID  10   /* int32[n]  lowest particle id of the bonded cluster */
+#define CHEM_STATE_POS_UNFOLDED 11 /* double[n*3] = pos + image*L                  */
+
+typedef struct chem_ctx chem_ctx;
+
+/* One chemical reaction  T1(min1,max1) + T2(min2,max2) -> N1(d1):N2(d2).
+ * Replaces espressopp.integrator.Reaction(type_1,type_2,delta_1,delta_2,min_state_1,
+ * max_state_1,min_state_2,max_state_2,rate,fpl,cutoff) + .intramolecular/.intraresidual/
+ * .is_virtual/.active, get_reaction_cutoff().min_cutoff and the PostProcessChangeProperty
+ * type change (reaction_setup.py:81-163). */
+typedef struct chem_reaction_desc {
+  int32_t type_1, type_2;
+  int32_t delta_1, delta_2;
+  int32_t min_state_1, max_state_1;   /* half-open [min,max) */
+  int32_t min_state_2, max_state_2;
+  double  rate;
+  double  cutoff;
+  double  min_cutoff;
+  int32_t intramolecular;             /* 1: partners may belong to one bonded cluster */
+  int32_t intraresidual;              /* 1: partners may share res_id                 */
+  int32_t is_virtual;                 /* 1: no bond is created                        */
+  int32_t active;
+  int32_t bond_list;                  /* handle of the arity-2 list receiving new bonds */
+  int32_t new_type_1, new_type_2;     /* -1: unchanged                                */
+  double  new_mass_1, new_mass_2;     /* used when the type changes                   */
+  double  new_q_1, new_q_2;
+} chem_reaction_desc;
+
+/* One accepted reaction event; chem_get_events returns them sorted by
+ * (step, min(id_a,id_b), max(id_a,id_b)). */
+typedef struct chem_event {
+  int64_t step;
+  int64_t id_a, id_b;     /* particle taking role type_1 / type_2 */
+  int32_t reaction;
+  int32_t pad;
+  double  r2;             /* fp64 squared distance at decision time */
+} chem_event;
+
+typedef struct chem_obs {
+  int64_t step;
+  int64_t npart;
+  double  ekin;
+  double  temperature;             /* 2 Ekin / (3 N), in energy units (k_B T)  */
+  double  epot_lj;                 /* VerletListLennardJones                   */
+  double  epot_tab;                /* VerletListTabulated                      */
+  double  epot_list[CHEM_MAX_LISTS];
+  int64_t list_size[CHEM_MAX_LISTS];
+  double  momentum[3];
+  double  virial_nb;               /* sum_pairs r.F of non-bonded              */
+} chem_obs;
+
+typedef struct chem_timers {
+  double run_wall_s;               /* wall seconds inside chem_run (== integratorLoop, start_simulation.py:779-781) */
+  int64_t steps;
+  int64_t rebuilds;
+  int64_t reaction_steps;
+  int64_t nlist_entries;           /* entries of the current full neighbour list */
+  int64_t nlist_capacity;
+  double  reaction_wall_s;
+  double  rebuild_wall_s;          /* host-observed; only reaction-step/forced rebuilds are synchronous */
+  double  pair_kernel_ms;          /* HIP-event time of all pair-force launches of the last chem_run */
+  int64_t pair_kernel_launches;
+} chem_timers;
+
+/* ---- life cycle ---------------------------------------------------------------------- */
+/* espressopp.System() + esutil.RNG + storage (start_simulation.py:148-163) */
+chem_ctx*   chem_create(int device_id, int precision);
+void        chem_destroy(chem_ctx* ctx);
+const char* chem_last_error(chem_ctx* ctx);      /* ctx may be NULL: last create error */
+int         chem_abi_version(void);
+
+/* ---- system set-up ------------------------------------------------------------------- */
+/* bc.OrthorhombicBC(rng, box)  start_simulation.py:162 */
+int chem_set_box(chem_ctx* ctx, const double L[3]);
+/* VerletList(system, cutoff=max_cutoff, ...) + system.skin  start_simulation.py:151,193-197 */
+int chem_set_cutoff(chem_ctx* ctx, double max_cutoff, double skin);
+/* integrator.dt = dt  start_simulation.py:166 */
+int chem_set_dt(chem_ctx* ctx, double dt);
+/* storage.addParticles(particle_list,'id','type','pos','mass','q','res_id','state',..)
+ * + decompose()  start_simulation.py:169-171, gromacs_topology.py:1418-1441.
+ * vel may be NULL (zeros); q, state, res_id may be NULL (0 / 0 / id). */
+int chem_set_particles(chem_ctx* ctx, int64_t n, const int64_t* id, const int32_t* type,
+                       const double* pos, const double* vel, const double* mass,
+                       const double* q, const int32_t* state, const int32_t* res_id);
+/* storage.modifyParticle(pid, 'type'|'state'|'mass', v)  examples/atrp_lj/hooks.py:63-65 */
+int chem_modify_particle(chem_ctx* ctx, int64_t id, int what /*CHEM_STATE_TYPE|STATE|MASS|RESID*/, double value);
+/* DynamicExcludeList(integrator, gt.exclusions)  start_simulation.py:189 */
+int chem_set_exclusions(chem_ctx* ctx, int64_t n, const int64_t* id_pairs);
+
+/* ---- non-bonded ---------------------------------------------------------------------- */
+/* interaction.LennardJones(epsilon, sigma, cutoff) via VerletListLennardJones.setPotential
+ * gromacs_topology.py:715-721.  shift_auto!=0: U(rc)=0. */
+int chem_nb_lj(chem_ctx* ctx, int t1, int t2, double eps, double sig, double rc, int shift_auto);
+/* interaction.Tabulated(itype=1, filename, cutoff) via VerletListTabulated.setPotential
+ * gromacs_topology.py:696-707; rows are the `r e f` lines of the .pot file
+ * (tools/convert_gromacs2espp.py:84-107), uniform spacing dr starting at r0. */
+int chem_nb_table(chem_ctx* ctx, int t1, int t2, int64_t nrow, double r0, double dr,
+                  const double* e, const double* f, double rc);
+
+/* ---- bonded lists -------------------------------------------------------------------- */
+/* FixedPairList/TripleList/QuadrupleList(storage) + FixedXListYyy(system, list, potential)
+ * gromacs_topology.py:949-961,1086-1096,1206-1224; reaction_setup.py:444-467.
+ * by_types!=0 -> the "Types" variant: parameters selected per entry from the CURRENT
+ * particle types (gromacs_topology.py:969-981).  Returns the list handle. */
+int chem_list_create(chem_ctx* ctx, int arity, int potential_kind, int by_types);
+/* addBonds/addTriples/addQuadruples: ids is n*arity particle ids */
+int chem_list_add(chem_ctx* ctx, int list, int64_t n, const int64_t* ids);
+/* plain list: t1..t4 ignored (pass -1); Types list: setPotential(type1,type2[,type3[,type4]],pot) */
+int chem_list_set_params(chem_ctx* ctx, int list, int t1, int t2, int t3, int t4,
+                         const double* p, int np);
+/* getAllBonds/getAllTriples/getAllQuadruples: out receives count*arity ids */
+int64_t chem_get_list(chem_ctx* ctx, int list, int64_t* out, int64_t cap_entries);
+
+/* ---- thermostat ---------------------------------------------------------------------- */
+/* integrator.LangevinThermostat: .temperature (=T*kb), .gamma  start_simulation.py:330-336.
+ * gamma<=0 or kT<0 switches it off (thermostat=no, Q6 in SURVEY). */
+int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t seed);
+
+/* ---- reactions ----------------------------------------------------------------------- */
+/* integrator.ChemicalReaction(system, vl, storage, tm, interval) + .nearest_mode
+ * + .max_per_interval  reaction_setup.py:416-427 */
+int chem_reaction_init(chem_ctx* ctx, int interval, int nearest, int max_per_interval, uint64_t seed);
+/* ar.add_reaction(Reaction(...))  reaction_setup.py:81-92,506; returns the reaction index */
+int chem_reaction_add(chem_ctx* ctx, const chem_reaction_desc* d);
+/* topology_manager.register_tuple/triplet/quadruplet(list, t1, t2[, t3[, t4]])
+ * start_simulation.py:395-440: new bonds spawn entries of `list` when the type tuple matches */
+int chem_topology_register(chem_ctx* ctx, int arity, int list, const int32_t* types);
+/* integrator.addExtension(ar) / ar.disconnect()  start_simulation.py:735-741,776-777 */
+int chem_reactions_enable(chem_ctx* ctx, int on);
+/* per-reaction rate update (Arrhenius hook, start_simulation.py:785-796) */
+int chem_reaction_set_rate(chem_ctx* ctx, int reaction, double rate);
+
+/* ---- the hot call -------------------------------------------------------------------- */
+/* integrator.run(n)  start_simulation.py:780.  No host round trip per step. */
+int chem_run(chem_ctx* ctx, int64_t nsteps);
+
+/* ---- read-back ----------------------------------------------------------------------- */
+int64_t chem_num_particles(chem_ctx* ctx);
+int64_t chem_get_step(chem_ctx* ctx);
+/* storage.getParticle(pid).pos/.v/.type/...; returns number of particles written */
+int64_t chem_get_state(chem_ctx* ctx, int what, void* out, int64_t cap_elems);
+int64_t chem_get_events(chem_ctx* ctx, chem_event* out, int64_t cap);
+int64_t chem_get_exclusions(chem_ctx* ctx, int64_t* out_pairs, int64_t cap_pairs);
+/* current Verlet list as unique id pairs (id_lo,id_hi), sorted; for tests/diagnostics */
+int64_t chem_get_verlet_pairs(chem_ctx* ctx, int64_t* out_pairs, int64_t cap_pairs);
+/* analysis.Temperature/KineticEnergy/PotentialEnergy/NFixedPairListEntries  start_simulation.py:453-493 */
+int chem_observe(chem_ctx* ctx, chem_obs* out);
+/* integrator.getTimers()/verletlist.get_timers()  start_simulation.py:1040-1076 */
+int chem_get_timers(chem_ctx* ctx, chem_timers* out);
+int chem_device_sync(chem_ctx* ctx);
+
+/* ---- tuning -------------------------------------------------------------------------- */
+/* neighbours per particle the list can hold (0 = automatic from density) */
+int chem_set_nlist_capacity(chem_ctx* ctx, int max_neighbours);
+/* generic integer knobs, see DESIGN.md ("tpp": lanes per particle in the pair kernel, ...) */
+int chem_set_option(chem_ctx* ctx, const char* name, double value);
+
+/* ---- multi-GPU (spatial domain decomposition, RCCL halo) ------------------------------ */
+/* storage.DomainDecomposition(system, nodeGrid, cellGrid) under mpirun
+ * start_simulation.py:152-163.  uid comes from chem_comm_unique_id on rank 0. */
+int chem_comm_unique_id(char uid[128]);
+int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], const char uid[128]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHEM_MI355_H */

@@ -1,0 +1,723 @@
+// md_oracle.cpp -- CPU restatement (fp64, scalar) of the ESPResSo++ algorithms that ChemLab's
+// hot path relies on.
+//
+// *** TEST INFRASTRUCTURE ONLY ***  Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may load this library.  The product (chemlab_amd/, libchem_mi355.so)
+// never links, imports or falls back to it.
+//
+// *** PARITY UNPINNED ***  The arithmetic of this path lives in the external, un-pinned
+// ESPResSo++ fork cgchemlab/espressopp (reference README.md:7-8), which is not vendored in
+// /root/reference and cannot be built or imported here.  The reference's own
+// tests pin nothing numerically on this path (src/tests/* only check parsing/replication
+// counts).  This file therefore restates the published algorithm from the ChemLab call-site
+// contract and the formulas in doc/topology.rst; it is validated by analytic known answers,
+// finite differences and conservation laws (tests/test_oracle_*.py), not by reference output.
+//
+// Citations (paths relative to /root/reference):
+//   velocity-Verlet loop / skin trigger ...... src/start_simulation.py:165-167,780 ; SURVEY 3.3
+//   Verlet list, exclusions ................... src/start_simulation.py:189-197
+//   Lennard-Jones ............................. doc/topology.rst:12-14 ; gromacs_topology.py:715-721
+//   Tabulated (itype=1, linear) ............... gromacs_topology.py:696-707 ; tools/convert_gromacs2espp.py:84-107
+//   Harmonic / FENE bonds ..................... doc/topology.rst:60 ; gromacs_topology.py:918-931
+//   AngularHarmonic / Cosine .................. doc/topology.rst:89-99 ; gromacs_topology.py:1073,1082
+//   Dihedrals ................................. doc/topology.rst:101-129 ; gromacs_topology.py:1185-1202
+//   Langevin thermostat ....................... src/start_simulation.py:330-336
+//   ChemicalReaction / Reaction ............... src/chemlab/reaction_setup.py:71-165,416-427
+//   TopologyManager / DynamicExcludeList ...... src/start_simulation.py:189,378-441
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
+// -ffp-contract=off keeps r^2 = dx*dx+dy*dy+dz*dz free of FMA so the reaction distance
+// test is bit-comparable with the device path.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../include/chem_mi355.h"
+#include "../include/chem_philox.h"
+
+namespace {
+
+struct Vec3 { double x, y, z; };
+static inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline Vec3 operator*(double s, Vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+static inline double dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static inline Vec3 cross(Vec3 a, Vec3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+struct PairPot {
+  int kind = 0;  // 0 none, 1 LJ, 2 table
+  double eps = 0, sig = 0, rc = 0, shift = 0;
+  // table
+  double r0 = 0, dr = 0;
+  std::vector<double> e, f;
+};
+
+struct BondedList {
+  int arity = 2, kind = 0, by_types = 0;
+  std::vector<int32_t> ent;             // arity tags per entry
+  std::set<std::vector<int32_t>> seen;  // canonical (orientation-free) keys for de-duplication
+  bool has_plain = false;
+  double plain[CHEM_MAX_POT_PARAMS] = {0};
+  std::map<std::vector<int>, std::vector<double>> typed;  // type tuple -> params
+  std::vector<std::vector<int>> registered;               // topology-manager type tuples
+};
+
+struct Orc {
+  std::string err;
+  double L[3] = {0, 0, 0};
+  double rc = 0, skin = 0, dt = 0;
+  int64_t n = 0;
+  std::vector<int64_t> id;      // tag -> external id (ascending)
+  std::unordered_map<int64_t, int32_t> id2tag;
+  std::vector<int32_t> type, state, res_id, mol_id;
+  std::vector<int32_t> img;     // 3 per particle
+  std::vector<Vec3> x, v, f;
+  std::vector<double> mass, q;
+  std::vector<std::set<int32_t>> excl;   // per tag
+  std::vector<std::set<int32_t>> graph;  // bond graph per tag
+  int ntypes = 0;
+  PairPot pp[CHEM_MAX_TYPES][CHEM_MAX_TYPES];
+  std::vector<BondedList> lists;
+  // thermostat
+  bool lang = false; double kT = 0, gamma = 0; uint64_t lang_seed = 0;
+  // reactions
+  bool react_init = false, react_on = false;
+  int interval = 0, nearest = 1, max_per_interval = 0; uint64_t react_seed = 0;
+  std::vector<chem_reaction_desc> reactions;
+  std::vector<chem_event> events;
+  // integrator state
+  int64_t step = 0;
+  bool resort = true;
+  double maxdist = 0;
+  std::vector<std::pair<int32_t, int32_t>> pairs;  // half Verlet list
+  int64_t rebuilds = 0, reaction_steps = 0;
+  double e_lj = 0, e_tab = 0, virial = 0;
+  double e_list[CHEM_MAX_LISTS] = {0};
+};
+
+static std::string g_err;
+
+static inline double wrap1(double d, double L) { return d - L * std::nearbyint(d / L); }
+static inline Vec3 minimg(const Orc& o, Vec3 d) {
+  return {wrap1(d.x, o.L[0]), wrap1(d.y, o.L[1]), wrap1(d.z, o.L[2])};
+}
+
+// fold positions into [0,L) and keep image counters (storage.decompose())
+static void fold(Orc& o) {
+  for (int64_t i = 0; i < o.n; ++i) {
+    double* p = &o.x[i].x;
+    for (int d = 0; d < 3; ++d) {
+      double s = std::floor(p[d] / o.L[d]);
+      if (s != 0.0) { p[d] -= s * o.L[d]; o.img[3 * i + d] += (int)s; }
+      if (p[d] >= o.L[d]) { p[d] -= o.L[d]; o.img[3 * i + d] += 1; }
+      if (p[d] < 0) { p[d] += o.L[d]; o.img[3 * i + d] -= 1; }
+    }
+  }
+}
+
+// Half Verlet list: every unordered pair with r^2 <= (rc+skin)^2 that is not excluded.
+static void build_pairs(Orc& o) {
+  fold(o);
+  o.pairs.clear();
+  const double rl = o.rc + o.skin, rl2 = rl * rl;
+  int nc[3];
+  for (int d = 0; d < 3; ++d) nc[d] = std::max(1, (int)std::floor(o.L[d] / rl));
+  auto test = [&](int32_t i, int32_t j) {
+    Vec3 d = minimg(o, o.x[i] - o.x[j]);
+    double r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+    if (r2 > rl2) return;
+    int32_t a = std::min(i, j), b = std::max(i, j);
+    if (o.excl[a].count(b)) return;
+    o.pairs.emplace_back(a, b);
+  };
+  if (nc[0] < 3 || nc[1] < 3 || nc[2] < 3) {
+    for (int32_t i = 0; i < o.n; ++i)
+      for (int32_t j = i + 1; j < o.n; ++j) test(i, j);
+  } else {
+    std::vector<std::vector<int32_t>> cells((size_t)nc[0] * nc[1] * nc[2]);
+    auto cid = [&](int cx, int cy, int cz) { return ((size_t)cz * nc[1] + cy) * nc[0] + cx; };
+    for (int32_t i = 0; i < o.n; ++i) {
+      int c[3];
+      const double* p = &o.x[i].x;
+      for (int d = 0; d < 3; ++d) {
+        c[d] = (int)(p[d] / o.L[d] * nc[d]);
+        if (c[d] >= nc[d]) c[d] = nc[d] - 1;
+        if (c[d] < 0) c[d] = 0;
+      }
+      cells[cid(c[0], c[1], c[2])].push_back(i);
+    }
+    for (int cz = 0; cz < nc[2]; ++cz)
+      for (int cy = 0; cy < nc[1]; ++cy)
+        for (int cx = 0; cx < nc[0]; ++cx) {
+          const auto& A = cells[cid(cx, cy, cz)];
+          for (size_t a = 0; a < A.size(); ++a)
+            for (size_t b = a + 1; b < A.size(); ++b) test(A[a], A[b]);
+          // 13 forward neighbours
+          for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+              for (int dx = -1; dx <= 1; ++dx) {
+                if (dz < 0 || (dz == 0 && dy < 0) || (dz == 0 && dy == 0 && dx <= 0)) continue;
+                int ox = (cx + dx + nc[0]) % nc[0], oy = (cy + dy + nc[1]) % nc[1],
+                    oz = (cz + dz + nc[2]) % nc[2];
+                const auto& B = cells[cid(ox, oy, oz)];
+                for (int32_t i : A)
+                  for (int32_t j : B) test(i, j);
+              }
+        }
+  }
+  std::sort(o.pairs.begin(), o.pairs.end());
+  o.maxdist = 0;
+  o.resort = false;
+  o.rebuilds++;
+}
+
+// ---- potentials ---------------------------------------------------------------------
+
+// returns force factor ff such that F_i = ff * r_ij (r_ij = x_i - x_j); adds energy to *e
+static inline bool pair_eval(const PairPot& p, double r2, double* ff, double* e) {
+  if (p.kind == 1) {
+    if (r2 > p.rc * p.rc) return false;
+    double frac2 = 1.0 / r2, s2 = p.sig * p.sig * frac2, s6 = s2 * s2 * s2;
+    *ff = 24.0 * p.eps * (2.0 * s6 * s6 - s6) * frac2;
+    *e = 4.0 * p.eps * (s6 * s6 - s6) + p.shift;
+    return true;
+  }
+  if (p.kind == 2) {
+    if (r2 > p.rc * p.rc) return false;
+    double r = std::sqrt(r2);
+    double t = (r - p.r0) / p.dr;
+    int64_t nrow = (int64_t)p.e.size();
+    double fe, ffv;
+    if (t <= 0) { fe = p.e[0]; ffv = p.f[0]; }
+    else if (t >= (double)(nrow - 1)) { fe = p.e[nrow - 1]; ffv = p.f[nrow - 1]; }
+    else {
+      int64_t k = (int64_t)t; double w = t - (double)k;
+      fe = p.e[k] + w * (p.e[k + 1] - p.e[k]);
+      ffv = p.f[k] + w * (p.f[k + 1] - p.f[k]);
+    }
+    *ff = ffv / r; *e = fe;
+    return true;
+  }
+  return false;
+}
+
+static const double* list_params(const Orc& o, const BondedList& l, const int32_t* tags) {
+  if (!l.by_types) return l.has_plain ? l.plain : nullptr;
+  std::vector<int> key(l.arity), rkey(l.arity);
+  for (int k = 0; k < l.arity; ++k) { key[k] = o.type[tags[k]]; rkey[l.arity - 1 - k] = key[k]; }
+  auto it = l.typed.find(key);
+  if (it == l.typed.end()) it = l.typed.find(rkey);
+  if (it == l.typed.end()) return nullptr;
+  return it->second.data();
+}
+
+static void bonded_forces(Orc& o) {
+  for (size_t li = 0; li < o.lists.size(); ++li) {
+    BondedList& l = o.lists[li];
+    double etot = 0;
+    size_t ne = l.ent.size() / l.arity;
+    for (size_t e = 0; e < ne; ++e) {
+      const int32_t* t = &l.ent[e * l.arity];
+      const double* p = list_params(o, l, t);
+      if (!p) continue;
+      if (l.arity == 2) {
+        Vec3 d = minimg(o, o.x[t[0]] - o.x[t[1]]);
+        double r = std::sqrt(dot(d, d)), ff = 0, u = 0;
+        if (l.kind == CHEM_POT_HARMONIC) {
+          double dr = r - p[1]; u = p[0] * dr * dr; ff = -2.0 * p[0] * dr / r;
+        } else if (l.kind == CHEM_POT_FENE) {
+          double dr = r - p[1], q = dr / p[2], den = 1.0 - q * q;
+          u = -0.5 * p[0] * p[2] * p[2] * std::log(den);
+          ff = -p[0] * dr / den / r;
+        }
+        o.f[t[0]] = o.f[t[0]] + ff * d; o.f[t[1]] = o.f[t[1]] - ff * d; etot += u;
+      } else if (l.arity == 3) {
+        Vec3 r1 = minimg(o, o.x[t[0]] - o.x[t[1]]), r2 = minimg(o, o.x[t[2]] - o.x[t[1]]);
+        double n1 = std::sqrt(dot(r1, r1)), n2 = std::sqrt(dot(r2, r2));
+        double c = dot(r1, r2) / (n1 * n2);
+        c = std::max(-1.0, std::min(1.0, c));
+        double th = std::acos(c), s = std::sqrt(1.0 - c * c);
+        if (s < 1e-9) s = 1e-9;
+        double u = 0, dU = 0;
+        if (l.kind == CHEM_POT_ANG_HARMONIC) { double d = th - p[1]; u = p[0] * d * d; dU = 2.0 * p[0] * d; }
+        else if (l.kind == CHEM_POT_ANG_COSINE) { u = p[0] * (1.0 + std::cos(th - p[1])); dU = -p[0] * std::sin(th - p[1]); }
+        double a = dU / s;
+        Vec3 fi = a * ((1.0 / (n1 * n2)) * r2 - (c / (n1 * n1)) * r1);
+        Vec3 fk = a * ((1.0 / (n1 * n2)) * r1 - (c / (n2 * n2)) * r2);
+        o.f[t[0]] = o.f[t[0]] + fi; o.f[t[2]] = o.f[t[2]] + fk;
+        o.f[t[1]] = o.f[t[1]] - (fi + fk); etot += u;
+      } else {
+        Vec3 b1 = minimg(o, o.x[t[1]] - o.x[t[0]]), b2 = minimg(o, o.x[t[2]] - o.x[t[1]]),
+             b3 = minimg(o, o.x[t[3]] - o.x[t[2]]);
+        Vec3 m = cross(b1, b2), nn = cross(b2, b3);
+        double m2 = dot(m, m), n2 = dot(nn, nn), lb2 = dot(b2, b2), lb = std::sqrt(lb2);
+        if (m2 < 1e-30 || n2 < 1e-30) continue;
+        double phi = std::atan2(lb * dot(b1, nn), dot(m, nn));
+        double u = 0, dU = 0;
+        if (l.kind == CHEM_POT_DIH_NCOS) {
+          u = p[0] * (1.0 + std::cos(p[2] * phi - p[1])); dU = -p[0] * p[2] * std::sin(p[2] * phi - p[1]);
+        } else if (l.kind == CHEM_POT_DIH_RB) {
+          double psi = phi - M_PI, cp = std::cos(psi), sp = std::sin(psi), pw = 1.0, dsum = 0;
+          for (int k = 0; k < 6; ++k) { u += p[k] * pw; if (k < 5) { dsum += (k + 1) * p[k + 1] * pw; } pw *= cp; }
+          dU = -sp * dsum;
+        }
+        // dphi/dx (Blondel & Karplus)
+        Vec3 g1 = (-lb / m2) * m, g4 = (lb / n2) * nn;
+        double s12 = dot(b1, b2) / lb2, s32 = dot(b3, b2) / lb2;
+        Vec3 g2 = {(-1.0 - s12) * g1.x + s32 * g4.x, (-1.0 - s12) * g1.y + s32 * g4.y, (-1.0 - s12) * g1.z + s32 * g4.z};
+        Vec3 g3 = {(-1.0 - s32) * g4.x + s12 * g1.x, (-1.0 - s32) * g4.y + s12 * g1.y, (-1.0 - s32) * g4.z + s12 * g1.z};
+        o.f[t[0]] = o.f[t[0]] - dU * g1; o.f[t[1]] = o.f[t[1]] - dU * g2;
+        o.f[t[2]] = o.f[t[2]] - dU * g3; o.f[t[3]] = o.f[t[3]] - dU * g4; etot += u;
+      }
+    }
+    o.e_list[li] = etot;
+  }
+}
+
+// phase: 0 = evaluation at run() start, 1 = in-loop evaluation of step index `istep`
+static void update_forces(Orc& o, int64_t istep, int phase) {
+  for (auto& f : o.f) f = {0, 0, 0};
+  o.e_lj = o.e_tab = o.virial = 0;
+  for (auto& pr : o.pairs) {
+    int32_t i = pr.first, j = pr.second;
+    const PairPot& p = o.pp[o.type[i]][o.type[j]];
+    if (!p.kind) continue;
+    Vec3 d = minimg(o, o.x[i] - o.x[j]);
+    double r2 = d.x * d.x + d.y * d.y + d.z * d.z, ff, e;
+    if (!pair_eval(p, r2, &ff, &e)) continue;
+    o.f[i] = o.f[i] + ff * d; o.f[j] = o.f[j] - ff * d;
+    (p.kind == 1 ? o.e_lj : o.e_tab) += e;
+    o.virial += ff * r2;
+  }
+  bonded_forces(o);
+  if (o.lang) {
+    for (int64_t i = 0; i < o.n; ++i) {
+      uint32_t r[4];
+      chem_philox::langevin_draw(o.lang_seed, (uint64_t)istep, (uint32_t)phase, (uint32_t)i, r);
+      double m = o.mass[i], pref = std::sqrt(24.0 * o.kT * o.gamma * m / o.dt);
+      double* f = &o.f[i].x; const double* v = &o.v[i].x;
+      for (int d = 0; d < 3; ++d) f[d] += -o.gamma * m * v[d] + pref * (chem_philox::u01(r[d]) - 0.5);
+    }
+  }
+}
+
+// ---- topology manager ---------------------------------------------------------------
+
+static std::vector<int32_t> canon_key(const int32_t* t, int arity) {
+  std::vector<int32_t> a(t, t + arity), b(arity);
+  for (int k = 0; k < arity; ++k) b[arity - 1 - k] = a[k];
+  return std::min(a, b);
+}
+
+static bool list_insert(BondedList& l, const int32_t* t) {
+  auto key = canon_key(t, l.arity);
+  if (!l.seen.insert(key).second) return false;
+  l.ent.insert(l.ent.end(), t, t + l.arity);
+  return true;
+}
+
+static void exclude(Orc& o, int32_t a, int32_t b) {
+  if (a == b) return;
+  o.excl[std::min(a, b)].insert(std::max(a, b));
+}
+
+// relabel the bonded cluster containing `start` with the minimum res_id / tag it holds
+static void merge_cluster(Orc& o, int32_t a, int32_t b) {
+  int32_t new_res = std::min(o.res_id[a], o.res_id[b]);
+  int32_t new_mol = std::min(o.mol_id[a], o.mol_id[b]);
+  // flood fill from a over the bond graph (a-b is already in the graph)
+  std::vector<int32_t> stack{a};
+  std::set<int32_t> vis{a};
+  while (!stack.empty()) {
+    int32_t p = stack.back(); stack.pop_back();
+    o.res_id[p] = new_res; o.mol_id[p] = new_mol;
+    for (int32_t nb : o.graph[p]) if (vis.insert(nb).second) stack.push_back(nb);
+  }
+}
+
+// try to place (t[0..arity)) into the first list of that arity whose registered type tuples match
+static void spawn_tuple(Orc& o, int arity, const int32_t* t) {
+  for (auto& l : o.lists) {
+    if (l.arity != arity) continue;
+    for (auto& reg : l.registered) {
+      bool fwd = true, rev = true;
+      for (int k = 0; k < arity; ++k) {
+        if (o.type[t[k]] != reg[k]) fwd = false;
+        if (o.type[t[arity - 1 - k]] != reg[k]) rev = false;
+      }
+      if (!fwd && !rev) continue;
+      int32_t tt[4];
+      for (int k = 0; k < arity; ++k) tt[k] = fwd ? t[k] : t[arity - 1 - k];
+      if (list_insert(l, tt)) exclude(o, tt[0], tt[arity - 1]);
+      return;
+    }
+  }
+}
+
+static void on_new_bonds(Orc& o, const std::vector<std::pair<int32_t, int32_t>>& nb) {
+  for (auto& e : nb) { o.graph[e.first].insert(e.second); o.graph[e.second].insert(e.first); }
+  for (auto& e : nb) merge_cluster(o, e.first, e.second);
+  for (auto& e : nb) {
+    int32_t a = e.first, b = e.second;
+    exclude(o, a, b);
+    // angles (n,a,b), (a,b,m)
+    for (int32_t n : o.graph[a]) if (n != b) { int32_t t[3] = {n, a, b}; spawn_tuple(o, 3, t); }
+    for (int32_t m : o.graph[b]) if (m != a) { int32_t t[3] = {a, b, m}; spawn_tuple(o, 3, t); }
+    // dihedrals (n',n,a,b), (n,a,b,m), (a,b,m,m')
+    for (int32_t n : o.graph[a]) if (n != b) {
+      for (int32_t n2 : o.graph[n]) if (n2 != a && n2 != b) { int32_t t[4] = {n2, n, a, b}; spawn_tuple(o, 4, t); }
+      for (int32_t m : o.graph[b]) if (m != a && m != n) { int32_t t[4] = {n, a, b, m}; spawn_tuple(o, 4, t); }
+    }
+    for (int32_t m : o.graph[b]) if (m != a)
+      for (int32_t m2 : o.graph[m]) if (m2 != b && m2 != a) { int32_t t[4] = {a, b, m, m2}; spawn_tuple(o, 4, t); }
+  }
+}
+
+// ---- reactions ----------------------------------------------------------------------
+
+struct Cand { int32_t a, b, r; double d2; uint32_t h; };
+
+static void react(Orc& o) {
+  o.reaction_steps++;
+  std::vector<Cand> c;
+  for (auto& pr : o.pairs) {
+    int32_t lo = pr.first, hi = pr.second;
+    for (size_t ri = 0; ri < o.reactions.size(); ++ri) {
+      const chem_reaction_desc& R = o.reactions[ri];
+      if (!R.active) continue;
+      auto ok = [&](int32_t a, int32_t b) {
+        return o.type[a] == R.type_1 && o.state[a] >= R.min_state_1 && o.state[a] < R.max_state_1 &&
+               o.type[b] == R.type_2 && o.state[b] >= R.min_state_2 && o.state[b] < R.max_state_2;
+      };
+      int32_t a, b;
+      if (ok(lo, hi)) { a = lo; b = hi; } else if (ok(hi, lo)) { a = hi; b = lo; } else continue;
+      if (!R.intraresidual && o.res_id[a] == o.res_id[b]) continue;
+      if (!R.intramolecular && o.mol_id[a] == o.mol_id[b]) continue;
+      Vec3 d = minimg(o, o.x[a] - o.x[b]);
+      double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
+      if (!(d2 >= R.min_cutoff * R.min_cutoff && d2 < R.cutoff * R.cutoff)) continue;
+      double prob = R.rate * o.dt * (double)o.interval;
+      uint32_t rr[4];
+      chem_philox::reaction_draw(o.react_seed, (uint64_t)o.step, (uint32_t)lo, (uint32_t)hi, (uint32_t)ri, rr);
+      if (prob < 1.0 && !(chem_philox::u01(rr[0]) < prob)) continue;
+      c.push_back({a, b, (int32_t)ri, d2, rr[1]});
+    }
+  }
+  const bool nearest = o.nearest != 0;
+  // UniqueA: every A keeps one partner (nearest, or pseudo-random by hash)
+  auto keyA = [&](const Cand& q) { return nearest ? std::make_tuple(q.d2, 0u, q.b, q.r) : std::make_tuple(0.0, q.h, q.b, q.r); };
+  auto keyB = [&](const Cand& q) { return nearest ? std::make_tuple(q.d2, 0u, q.a, q.r) : std::make_tuple(0.0, q.h, q.a, q.r); };
+  {
+    std::map<int32_t, Cand> best;
+    for (auto& q : c) { auto it = best.find(q.a); if (it == best.end() || keyA(q) < keyA(it->second)) best[q.a] = q; }
+    c.clear(); for (auto& kv : best) c.push_back(kv.second);
+  }
+  {  // UniqueB
+    std::map<int32_t, Cand> best;
+    for (auto& q : c) { auto it = best.find(q.b); if (it == best.end() || keyB(q) < keyB(it->second)) best[q.b] = q; }
+    c.clear(); for (auto& kv : best) c.push_back(kv.second);
+  }
+  // one event per particle: greedy over (d2|hash, a) order
+  std::sort(c.begin(), c.end(), [&](const Cand& p, const Cand& q) {
+    return nearest ? std::make_tuple(p.d2, p.a) < std::make_tuple(q.d2, q.a)
+                   : std::make_tuple(p.h, p.a) < std::make_tuple(q.h, q.a);
+  });
+  std::vector<char> used(o.n, 0);
+  std::vector<Cand> acc;
+  for (auto& q : c) { if (used[q.a] || used[q.b]) continue; used[q.a] = used[q.b] = 1; acc.push_back(q); }
+  std::sort(acc.begin(), acc.end(), [](const Cand& p, const Cand& q) {
+    return std::make_pair(std::min(p.a, p.b), std::max(p.a, p.b)) < std::make_pair(std::min(q.a, q.b), std::max(q.a, q.b));
+  });
+  // apply
+  std::vector<std::pair<int32_t, int32_t>> newbonds;
+  std::vector<int> bond_list_of;
+  for (auto& q : acc) {
+    const chem_reaction_desc& R = o.reactions[q.r];
+    o.state[q.a] += R.delta_1; o.state[q.b] += R.delta_2;
+    if (R.new_type_1 >= 0 && R.new_type_1 != o.type[q.a]) { o.type[q.a] = R.new_type_1; o.mass[q.a] = R.new_mass_1; o.q[q.a] = R.new_q_1; }
+    if (R.new_type_2 >= 0 && R.new_type_2 != o.type[q.b]) { o.type[q.b] = R.new_type_2; o.mass[q.b] = R.new_mass_2; o.q[q.b] = R.new_q_2; }
+    o.events.push_back({o.step, o.id[q.a], o.id[q.b], q.r, 0, q.d2});
+    if (!R.is_virtual) {
+      int32_t t[2] = {q.a, q.b};
+      if (list_insert(o.lists[R.bond_list], t)) newbonds.emplace_back(q.a, q.b);
+    }
+  }
+  if (!newbonds.empty()) { on_new_bonds(o, newbonds); o.resort = true; }
+}
+
+// ---- integrator ---------------------------------------------------------------------
+
+static void run(Orc& o, int64_t nsteps) {
+  if (o.resort) build_pairs(o);
+  update_forces(o, o.step, 0);
+  for (int64_t s = 0; s < nsteps; ++s) {
+    double max2 = 0;
+    for (int64_t i = 0; i < o.n; ++i) {
+      double hm = 0.5 * o.dt / o.mass[i];
+      o.v[i] = o.v[i] + hm * o.f[i];
+      Vec3 dx = o.dt * o.v[i];
+      o.x[i] = o.x[i] + dx;
+      double d2 = dx.x * dx.x + dx.y * dx.y + dx.z * dx.z;
+      if (d2 > max2) max2 = d2;
+    }
+    o.maxdist += std::sqrt(max2);
+    if (o.maxdist > 0.5 * o.skin || o.resort) build_pairs(o);
+    update_forces(o, o.step, 1);
+    for (int64_t i = 0; i < o.n; ++i) o.v[i] = o.v[i] + (0.5 * o.dt / o.mass[i]) * o.f[i];
+    o.step++;
+    if (o.react_on && o.interval > 0 && o.step % o.interval == 0) react(o);
+  }
+}
+
+}  // namespace
+
+// =====================================================================================
+// C API (mirrors include/chem_mi355.h with the orc_ prefix)
+// =====================================================================================
+#define O(ctx) (*reinterpret_cast<Orc*>(ctx))
+#define FAIL(code, msg) do { o.err = (msg); return (code); } while (0)
+
+extern "C" {
+
+void* orc_create() { return new Orc(); }
+void orc_destroy(void* c) { delete reinterpret_cast<Orc*>(c); }
+const char* orc_last_error(void* c) { return c ? O(c).err.c_str() : g_err.c_str(); }
+
+int orc_set_box(void* c, const double L[3]) { Orc& o = O(c); for (int d = 0; d < 3; ++d) { if (!(L[d] > 0)) FAIL(CHEM_EINVAL, "box"); o.L[d] = L[d]; } return 0; }
+int orc_set_cutoff(void* c, double rc, double skin) { Orc& o = O(c); if (!(rc > 0) || skin < 0) FAIL(CHEM_EINVAL, "cutoff"); o.rc = rc; o.skin = skin; o.resort = true; return 0; }
+int orc_set_dt(void* c, double dt) { O(c).dt = dt; return 0; }
+
+int orc_set_particles(void* c, int64_t n, const int64_t* id, const int32_t* type, const double* pos,
+                      const double* vel, const double* mass, const double* q, const int32_t* state,
+                      const int32_t* res_id) {
+  Orc& o = O(c);
+  if (n <= 0 || !id || !type || !pos || !mass) FAIL(CHEM_EINVAL, "set_particles: null/empty");
+  std::vector<int64_t> order(n);
+  for (int64_t i = 0; i < n; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return id[a] < id[b]; });
+  o.n = n; o.id.resize(n); o.type.resize(n); o.state.resize(n); o.res_id.resize(n); o.mol_id.resize(n);
+  o.x.resize(n); o.v.resize(n); o.f.assign(n, {0, 0, 0}); o.mass.resize(n); o.q.resize(n);
+  o.img.assign(3 * n, 0); o.excl.assign(n, {}); o.graph.assign(n, {}); o.id2tag.clear();
+  for (int64_t t = 0; t < n; ++t) {
+    int64_t s = order[t];
+    if (t && id[s] == o.id[t - 1]) FAIL(CHEM_EINVAL, "duplicate particle id");
+    if (type[s] < 0 || type[s] >= CHEM_MAX_TYPES) FAIL(CHEM_EINVAL, "type out of range");
+    o.id[t] = id[s]; o.id2tag[id[s]] = (int32_t)t; o.type[t] = type[s];
+    o.x[t] = {pos[3 * s], pos[3 * s + 1], pos[3 * s + 2]};
+    o.v[t] = vel ? Vec3{vel[3 * s], vel[3 * s + 1], vel[3 * s + 2]} : Vec3{0, 0, 0};
+    o.mass[t] = mass[s]; o.q[t] = q ? q[s] : 0.0;
+    o.state[t] = state ? state[s] : 0; o.res_id[t] = res_id ? res_id[s] : (int32_t)id[s];
+    o.mol_id[t] = (int32_t)t;
+  }
+  o.resort = true;
+  return 0;
+}
+
+static int tag_of(Orc& o, int64_t id) { auto it = o.id2tag.find(id); return it == o.id2tag.end() ? -1 : it->second; }
+
+int orc_modify_particle(void* c, int64_t id, int what, double value) {
+  Orc& o = O(c); int t = tag_of(o, id); if (t < 0) FAIL(CHEM_EINVAL, "unknown id");
+  if (what == CHEM_STATE_TYPE) o.type[t] = (int)value; else if (what == CHEM_STATE_STATE) o.state[t] = (int)value;
+  else if (what == CHEM_STATE_MASS) o.mass[t] = value; else if (what == CHEM_STATE_RESID) o.res_id[t] = (int)value;
+  else FAIL(CHEM_EINVAL, "modify: what"); return 0;
+}
+
+int orc_set_exclusions(void* c, int64_t n, const int64_t* p) {
+  Orc& o = O(c);
+  for (auto& s : o.excl) s.clear();
+  for (int64_t k = 0; k < n; ++k) {
+    int a = tag_of(o, p[2 * k]), b = tag_of(o, p[2 * k + 1]);
+    if (a < 0 || b < 0) FAIL(CHEM_EINVAL, "exclusion: unknown id");
+    exclude(o, a, b);
+  }
+  o.resort = true; return 0;
+}
+
+int orc_nb_lj(void* c, int t1, int t2, double eps, double sig, double rc, int shift_auto) {
+  Orc& o = O(c);
+  if (t1 < 0 || t2 < 0 || t1 >= CHEM_MAX_TYPES || t2 >= CHEM_MAX_TYPES) FAIL(CHEM_EINVAL, "type");
+  PairPot p; p.kind = (sig > 0 && rc > 0) ? 1 : 0; p.eps = eps; p.sig = sig; p.rc = rc;
+  if (p.kind && shift_auto) { double s2 = sig * sig / (rc * rc), s6 = s2 * s2 * s2; p.shift = -4.0 * eps * (s6 * s6 - s6); }
+  o.pp[t1][t2] = p; o.pp[t2][t1] = p; return 0;
+}
+
+int orc_nb_table(void* c, int t1, int t2, int64_t nrow, double r0, double dr, const double* e, const double* f, double rc) {
+  Orc& o = O(c);
+  if (t1 < 0 || t2 < 0 || t1 >= CHEM_MAX_TYPES || t2 >= CHEM_MAX_TYPES || nrow < 2 || !(dr > 0)) FAIL(CHEM_EINVAL, "table");
+  PairPot p; p.kind = 2; p.rc = rc; p.r0 = r0; p.dr = dr; p.e.assign(e, e + nrow); p.f.assign(f, f + nrow);
+  o.pp[t1][t2] = p; o.pp[t2][t1] = p; return 0;
+}
+
+int orc_list_create(void* c, int arity, int kind, int by_types) {
+  Orc& o = O(c);
+  if (arity < 2 || arity > 4 || (int)o.lists.size() >= CHEM_MAX_LISTS) FAIL(CHEM_EINVAL, "list_create");
+  BondedList l; l.arity = arity; l.kind = kind; l.by_types = by_types; o.lists.push_back(l);
+  return (int)o.lists.size() - 1;
+}
+
+int orc_list_add(void* c, int list, int64_t n, const int64_t* ids) {
+  Orc& o = O(c);
+  if (list < 0 || list >= (int)o.lists.size()) FAIL(CHEM_EINVAL, "list handle");
+  BondedList& l = o.lists[list];
+  std::vector<std::pair<int32_t, int32_t>> nb;
+  for (int64_t e = 0; e < n; ++e) {
+    int32_t t[4];
+    for (int k = 0; k < l.arity; ++k) { int tg = tag_of(o, ids[e * l.arity + k]); if (tg < 0) FAIL(CHEM_EINVAL, "list_add: unknown id"); t[k] = tg; }
+    if (list_insert(l, t) && l.arity == 2) nb.emplace_back(t[0], t[1]);
+  }
+  // bonds feed the topology graph (TopologyManager.observe_tuple + initialize_topology)
+  for (auto& e : nb) { o.graph[e.first].insert(e.second); o.graph[e.second].insert(e.first); }
+  for (auto& e : nb) {
+    int32_t new_mol = std::min(o.mol_id[e.first], o.mol_id[e.second]);
+    std::vector<int32_t> st{e.first}; std::set<int32_t> vis{e.first};
+    while (!st.empty()) { int32_t p = st.back(); st.pop_back(); o.mol_id[p] = new_mol; for (int32_t q : o.graph[p]) if (vis.insert(q).second) st.push_back(q); }
+  }
+  return 0;
+}
+
+int orc_list_set_params(void* c, int list, int t1, int t2, int t3, int t4, const double* p, int np) {
+  Orc& o = O(c);
+  if (list < 0 || list >= (int)o.lists.size() || np < 1 || np > CHEM_MAX_POT_PARAMS) FAIL(CHEM_EINVAL, "list_set_params");
+  BondedList& l = o.lists[list];
+  if (!l.by_types) { std::fill(l.plain, l.plain + CHEM_MAX_POT_PARAMS, 0.0); std::copy(p, p + np, l.plain); l.has_plain = true; return 0; }
+  int tt[4] = {t1, t2, t3, t4};
+  std::vector<int> key(tt, tt + l.arity);
+  std::vector<double> v(CHEM_MAX_POT_PARAMS, 0.0); std::copy(p, p + np, v.begin());
+  l.typed[key] = v; return 0;
+}
+
+int64_t orc_get_list(void* c, int list, int64_t* out, int64_t cap) {
+  Orc& o = O(c);
+  if (list < 0 || list >= (int)o.lists.size()) FAIL(CHEM_EINVAL, "list handle");
+  BondedList& l = o.lists[list]; int64_t ne = (int64_t)l.ent.size() / l.arity;
+  if (!out) return ne; if (cap < ne) FAIL(CHEM_ENOSPC, "get_list cap");
+  for (size_t k = 0; k < l.ent.size(); ++k) out[k] = o.id[l.ent[k]];
+  return ne;
+}
+
+int orc_thermostat_langevin(void* c, double kT, double gamma, uint64_t seed) {
+  Orc& o = O(c); o.lang = (gamma > 0 && kT >= 0); o.kT = kT; o.gamma = gamma; o.lang_seed = seed; return 0;
+}
+
+int orc_reaction_init(void* c, int interval, int nearest, int max_per_interval, uint64_t seed) {
+  Orc& o = O(c); if (interval <= 0) FAIL(CHEM_EINVAL, "interval");
+  if (max_per_interval > 0) FAIL(CHEM_ENOTIMPL, "max_per_interval");
+  o.react_init = true; o.interval = interval; o.nearest = nearest; o.max_per_interval = max_per_interval; o.react_seed = seed; return 0;
+}
+
+int orc_reaction_add(void* c, const chem_reaction_desc* d) {
+  Orc& o = O(c);
+  if (!o.react_init) FAIL(CHEM_ESTATE, "reaction_init first");
+  if (!d->is_virtual && (d->bond_list < 0 || d->bond_list >= (int)o.lists.size() || o.lists[d->bond_list].arity != 2)) FAIL(CHEM_EINVAL, "bond_list");
+  o.reactions.push_back(*d); return (int)o.reactions.size() - 1;
+}
+
+int orc_topology_register(void* c, int arity, int list, const int32_t* types) {
+  Orc& o = O(c);
+  if (list < 0 || list >= (int)o.lists.size() || o.lists[list].arity != arity) FAIL(CHEM_EINVAL, "topology_register");
+  o.lists[list].registered.emplace_back(types, types + arity); return 0;
+}
+
+int orc_reactions_enable(void* c, int on) { O(c).react_on = on != 0; return 0; }
+int orc_reaction_set_rate(void* c, int r, double rate) { Orc& o = O(c); if (r < 0 || r >= (int)o.reactions.size()) FAIL(CHEM_EINVAL, "reaction"); o.reactions[r].rate = rate; return 0; }
+
+int orc_run(void* c, int64_t nsteps) {
+  Orc& o = O(c);
+  if (o.n == 0 || !(o.L[0] > 0) || !(o.rc > 0) || !(o.dt > 0)) FAIL(CHEM_ESTATE, "run: system incomplete");
+  run(o, nsteps); return 0;
+}
+
+int64_t orc_num_particles(void* c) { return O(c).n; }
+int64_t orc_get_step(void* c) { return O(c).step; }
+
+int64_t orc_get_state(void* c, int what, void* out, int64_t cap) {
+  Orc& o = O(c); int64_t n = o.n;
+  int per = (what == CHEM_STATE_POS || what == CHEM_STATE_VEL || what == CHEM_STATE_FORCE || what == CHEM_STATE_IMAGE || what == CHEM_STATE_POS_UNFOLDED) ? 3 : 1;
+  if (cap < n * per) FAIL(CHEM_ENOSPC, "get_state cap");
+  double* d = (double*)out; int32_t* i32 = (int32_t*)out; int64_t* i64 = (int64_t*)out;
+  for (int64_t i = 0; i < n; ++i) {
+    switch (what) {
+      case CHEM_STATE_POS: { Vec3 p = o.x[i]; double* q = &p.x; for (int k = 0; k < 3; ++k) { double s = std::floor(q[k] / o.L[k]); q[k] -= s * o.L[k]; if (q[k] >= o.L[k]) q[k] -= o.L[k]; d[3 * i + k] = q[k]; } break; }
+      case CHEM_STATE_POS_UNFOLDED: { const double* q = &o.x[i].x; for (int k = 0; k < 3; ++k) d[3 * i + k] = q[k] + o.img[3 * i + k] * o.L[k]; break; }
+      case CHEM_STATE_VEL: d[3 * i] = o.v[i].x; d[3 * i + 1] = o.v[i].y; d[3 * i + 2] = o.v[i].z; break;
+      case CHEM_STATE_FORCE: d[3 * i] = o.f[i].x; d[3 * i + 1] = o.f[i].y; d[3 * i + 2] = o.f[i].z; break;
+      case CHEM_STATE_TYPE: i32[i] = o.type[i]; break;
+      case CHEM_STATE_STATE: i32[i] = o.state[i]; break;
+      case CHEM_STATE_RESID: i32[i] = o.res_id[i]; break;
+      case CHEM_STATE_MOLID: i32[i] = (int32_t)o.id[o.mol_id[i]]; break;
+      case CHEM_STATE_MASS: d[i] = o.mass[i]; break;
+      case CHEM_STATE_ID: i64[i] = o.id[i]; break;
+      case CHEM_STATE_IMAGE: for (int k = 0; k < 3; ++k) i32[3 * i + k] = o.img[3 * i + k]; break;
+      default: FAIL(CHEM_EINVAL, "get_state: what");
+    }
+  }
+  return n;
+}
+
+int64_t orc_get_events(void* c, chem_event* out, int64_t cap) {
+  Orc& o = O(c); int64_t n = (int64_t)o.events.size();
+  if (!out) return n; if (cap < n) FAIL(CHEM_ENOSPC, "events cap");
+  std::copy(o.events.begin(), o.events.end(), out); return n;
+}
+
+int64_t orc_get_exclusions(void* c, int64_t* out, int64_t cap) {
+  Orc& o = O(c); int64_t n = 0; for (auto& s : o.excl) n += (int64_t)s.size();
+  if (!out) return n; if (cap < n) FAIL(CHEM_ENOSPC, "excl cap");
+  int64_t k = 0; for (int64_t a = 0; a < o.n; ++a) for (int32_t b : o.excl[a]) { out[2 * k] = o.id[a]; out[2 * k + 1] = o.id[b]; ++k; }
+  return n;
+}
+
+int64_t orc_get_verlet_pairs(void* c, int64_t* out, int64_t cap) {
+  Orc& o = O(c);
+  if (o.resort) build_pairs(o);
+  int64_t n = (int64_t)o.pairs.size();
+  if (!out) return n; if (cap < n) FAIL(CHEM_ENOSPC, "pairs cap");
+  for (int64_t k = 0; k < n; ++k) { out[2 * k] = o.id[o.pairs[k].first]; out[2 * k + 1] = o.id[o.pairs[k].second]; }
+  return n;
+}
+
+// forces/energies of the current configuration without advancing time (no thermostat noise)
+int orc_observe(void* c, chem_obs* out) {
+  Orc& o = O(c);
+  if (o.resort) build_pairs(o);
+  bool lang = o.lang; o.lang = false;
+  std::vector<Vec3> fsave = o.f;
+  update_forces(o, o.step, 0);
+  o.f = fsave; o.lang = lang;
+  std::memset(out, 0, sizeof(*out));
+  out->step = o.step; out->npart = o.n;
+  double ek = 0, p[3] = {0, 0, 0};
+  for (int64_t i = 0; i < o.n; ++i) { ek += 0.5 * o.mass[i] * dot(o.v[i], o.v[i]); p[0] += o.mass[i] * o.v[i].x; p[1] += o.mass[i] * o.v[i].y; p[2] += o.mass[i] * o.v[i].z; }
+  out->ekin = ek; out->temperature = 2.0 * ek / (3.0 * (double)o.n);
+  out->epot_lj = o.e_lj; out->epot_tab = o.e_tab; out->virial_nb = o.virial;
+  for (size_t l = 0; l < o.lists.size(); ++l) { out->epot_list[l] = o.e_list[l]; out->list_size[l] = (int64_t)o.lists[l].ent.size() / o.lists[l].arity; }
+  for (int k = 0; k < 3; ++k) out->momentum[k] = p[k];
+  return 0;
+}
+
+// evaluate forces of the current configuration into the force array (for force parity tests)
+int orc_compute_forces(void* c) {
+  Orc& o = O(c);
+  if (o.resort) build_pairs(o);
+  update_forces(o, o.step, 0);
+  return 0;
+}
+
+int orc_get_timers(void* c, chem_timers* t) { Orc& o = O(c); std::memset(t, 0, sizeof(*t)); t->steps = o.step; t->rebuilds = o.rebuilds; t->reaction_steps = o.reaction_steps; t->nlist_entries = 2 * (int64_t)o.pairs.size(); return 0; }
+
+}  // extern "C"
+
+// raw Philox block for the known-answer test (tests/test_philox.py)
+extern "C" void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  chem_philox::philox4x32_10(ctr, key, out);
+}

@@ -1,0 +1,138 @@
+"""Pins the CPU restatement (oracle/) with closed-form answers from doc/topology.rst of the
+reference and with F = -grad U by central differences.  The reference ships no numeric
+fixtures for this path: these known answers are what anchors the oracle."""
+import numpy as np
+import pytest
+
+from chemlab_amd.workloads import synthetic_table
+from helpers import fd_forces, forces_energy, setup_small, total_epot
+
+
+def test_lj_two_body_closed_form(make_oracle):
+    # doc/topology.rst:12-14  U = 4 eps ((s/r)^12 - (s/r)^6), shifted so that U(rc) = 0
+    eps, sig, rc, r = 1.3, 0.9, 2.5, 1.1
+    e = setup_small(make_oracle(), [[5, 5, 5], [5 + r, 5, 5]])
+    e.nb_lj(0, 0, eps, sig, rc, True)
+    f, obs = forces_energy(e)
+    sr6 = (sig / r) ** 6
+    u = 4 * eps * (sr6 ** 2 - sr6) - 4 * eps * ((sig / rc) ** 12 - (sig / rc) ** 6)
+    fmag = 24 * eps * (2 * sr6 ** 2 - sr6) / r
+    assert obs["epot_lj"] == pytest.approx(u, rel=1e-13)
+    assert f[1, 0] == pytest.approx(fmag, rel=1e-13) and f[0, 0] == pytest.approx(-fmag, rel=1e-13)
+    assert np.allclose(f[:, 1:], 0)
+
+
+def test_lj_cutoff_and_no_interaction_for_sigma_zero(make_oracle):
+    e = setup_small(make_oracle(), [[5, 5, 5], [7.6, 5, 5]], skin=0.3)
+    e.nb_lj(0, 0, 1.0, 1.0, 2.5, True)
+    f, obs = forces_energy(e)
+    assert np.all(f == 0) and obs["epot_lj"] == 0
+    # sigma <= 0 switches the pair off (gromacs_topology.py:715; chain_growth_catalytic/topol.top:16-17)
+    e2 = setup_small(make_oracle(), [[5, 5, 5], [6.0, 5, 5]], types=np.array([0, 1], np.int32))
+    e2.nb_lj(0, 0, 1.0, 1.0, 2.5, True)
+    e2.nb_lj(0, 1, 0.0, 0.0, 2.5, True)
+    f, obs = forces_energy(e2)
+    assert np.all(f == 0)
+
+
+def test_lj_periodic_minimum_image(make_oracle):
+    e = setup_small(make_oracle(), [[0.2, 5, 5], [19.7, 5, 5]], box=20.0)
+    e.nb_lj(0, 0, 1.0, 1.0, 2.5, False)
+    f, obs = forces_energy(e)
+    r = 0.5
+    assert f[0, 0] == pytest.approx(24 * (2 / r ** 12 - 1 / r ** 6) / r, rel=1e-12)  # pushed to +x
+    assert f[0, 0] > 0 and f[1, 0] == pytest.approx(-f[0, 0])
+
+
+def test_harmonic_bond_closed_form(make_oracle):
+    # U = K (r - r0)^2 (ESPResSo++ convention = GROMACS k/2, gromacs_topology.py:918; doc/topology.rst:60)
+    K, r0, r = 30.0, 0.97, 1.2
+    e = setup_small(make_oracle(), [[5, 5, 5], [5, 5 + r, 5]])
+    h = e.list_create(2, "HARMONIC")
+    e.list_set_params(h, [K, r0])
+    e.list_add(h, [[1, 2]])
+    f, obs = forces_energy(e)
+    assert obs["epot_list"][0] == pytest.approx(K * (r - r0) ** 2, rel=1e-13)
+    assert f[1, 1] == pytest.approx(-2 * K * (r - r0), rel=1e-13)
+    assert f[0, 1] == pytest.approx(+2 * K * (r - r0), rel=1e-13)
+
+
+def test_fene_bond_closed_form(make_oracle):
+    K, r0, rmax, r = 30.0, 0.0, 1.5, 1.0
+    e = setup_small(make_oracle(), [[5, 5, 5], [5 + r, 5, 5]])
+    h = e.list_create(2, "FENE")
+    e.list_set_params(h, [K, r0, rmax])
+    e.list_add(h, [[1, 2]])
+    f, obs = forces_energy(e)
+    assert obs["epot_list"][0] == pytest.approx(-0.5 * K * rmax ** 2 * np.log(1 - (r / rmax) ** 2), rel=1e-13)
+    assert f[1, 0] == pytest.approx(-K * r / (1 - (r / rmax) ** 2), rel=1e-13)
+
+
+@pytest.mark.parametrize("kind,params", [("ANG_HARMONIC", [2.5, np.deg2rad(119.0)]), ("ANG_COSINE", [3.0, np.deg2rad(140.0)])])
+def test_angle_energy_and_fd(make_oracle, kind, params):
+    pos = np.array([[5.9, 5.1, 5.0], [5.0, 5.0, 5.2], [5.3, 5.8, 4.7]])
+
+    def build(e, p):
+        setup_small(e, p)
+        h = e.list_create(3, kind)
+        e.list_set_params(h, params)
+        e.list_add(h, [[1, 2, 3]])
+    e = make_oracle()
+    build(e, pos)
+    f, obs = forces_energy(e)
+    r1, r2 = pos[0] - pos[1], pos[2] - pos[1]
+    th = np.arccos(r1 @ r2 / np.linalg.norm(r1) / np.linalg.norm(r2))
+    u = params[0] * (th - params[1]) ** 2 if kind == "ANG_HARMONIC" else params[0] * (1 + np.cos(th - params[1]))
+    assert obs["epot_list"][0] == pytest.approx(u, rel=1e-12)
+    assert np.allclose(f, fd_forces(make_oracle, build, pos), rtol=1e-6, atol=1e-7)
+    assert np.allclose(f.sum(0), 0, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind,params", [("DIH_NCOS", [2.0, np.deg2rad(30.0), 3.0]), ("DIH_RB", [1.0, -0.5, 0.8, 0.3, -0.2, 0.1])])
+def test_dihedral_energy_and_fd(make_oracle, kind, params):
+    pos = np.array([[5.0, 5.0, 5.0], [5.9, 5.2, 5.1], [6.2, 6.1, 5.4], [7.1, 6.3, 6.2]])
+
+    def build(e, p):
+        setup_small(e, p)
+        h = e.list_create(4, kind)
+        e.list_set_params(h, params)
+        e.list_add(h, [[1, 2, 3, 4]])
+    e = make_oracle()
+    build(e, pos)
+    f, obs = forces_energy(e)
+    b1, b2, b3 = pos[1] - pos[0], pos[2] - pos[1], pos[3] - pos[2]
+    m, n = np.cross(b1, b2), np.cross(b2, b3)
+    phi = np.arctan2(np.linalg.norm(b2) * (b1 @ n), m @ n)
+    if kind == "DIH_NCOS":
+        u = params[0] * (1 + np.cos(params[2] * phi - params[1]))
+    else:
+        u = sum(c * np.cos(phi - np.pi) ** k for k, c in enumerate(params))
+    assert obs["epot_list"][0] == pytest.approx(u, rel=1e-12)
+    assert np.allclose(f, fd_forces(make_oracle, build, pos), rtol=1e-6, atol=1e-7)
+    assert np.allclose(f.sum(0), 0, atol=1e-12)
+
+
+def test_table_linear_interpolation(make_oracle):
+    # Tabulated(itype=1): linear between rows of the r e f table (.pot rows start at dr)
+    r0, dr, etab, ftab = synthetic_table(nrow=750, dr=0.002, rc=1.4)
+    r = 0.7313
+    e = setup_small(make_oracle(), [[5, 5, 5], [5, 5, 5 + r]], rc=1.4, skin=0.1)
+    e.nb_table(0, 0, r0, dr, etab, ftab, 1.4)
+    f, obs = forces_energy(e)
+    t = (r - r0) / dr
+    k = int(t)
+    w = t - k
+    assert obs["epot_tab"] == pytest.approx(etab[k] + w * (etab[k + 1] - etab[k]), rel=1e-12)
+    assert f[1, 2] == pytest.approx(ftab[k] + w * (ftab[k + 1] - ftab[k]), rel=1e-12)
+    assert f[0, 2] == pytest.approx(-f[1, 2])
+
+
+def test_typed_list_uses_current_types(make_oracle):
+    # "Types" lists pick parameters from the particle types at evaluation time (gromacs_topology.py:969-981)
+    e = setup_small(make_oracle(), [[5, 5, 5], [6.1, 5, 5], [7.3, 5, 5]], types=np.array([0, 1, 1], np.int32))
+    h = e.list_create(2, "HARMONIC", by_types=True)
+    e.list_set_params(h, [10.0, 1.0], types=(0, 1))
+    e.list_set_params(h, [20.0, 1.1], types=(1, 1))
+    e.list_add(h, [[1, 2], [2, 3]])
+    _, obs = forces_energy(e)
+    assert obs["epot_list"][0] == pytest.approx(10.0 * 0.1 ** 2 + 20.0 * 0.1 ** 2, rel=1e-10)
