@@ -79,6 +79,7 @@ struct Ctx {
   virtual int64_t verlet_pairs(int64_t* out, int64_t cap) = 0;
   virtual void modify_particle(int tag, int what, double value) = 0;
   virtual void sync() = 0;
+  virtual void refresh_timers() {}
 };
 
 template <typename R> struct CtxT : Ctx {
@@ -568,6 +569,13 @@ template <typename R> struct CtxT : Ctx {
     return m;
   }
 
+  void refresh_timers() override {
+    if (!device_ready || particles_dirty) return;
+    std::vector<int> hn; nn.download(hn, n, stream);
+    long long tot = 0; for (int v : hn) tot += v;
+    tm.nlist_entries = tot; tm.nlist_capacity = S;
+  }
+
   void modify_particle(int t, int what, double value) override {
     if (!device_ready || particles_dirty) return;  // host mirror only; uploaded later
     int idx = 0;
@@ -890,6 +898,7 @@ int chem_observe(chem_ctx* ctx, chem_obs* out) { API_BEGIN REQUIRE(out, CHEM_EIN
 int chem_get_timers(chem_ctx* ctx, chem_timers* out) {
   API_BEGIN
   REQUIRE(out, CHEM_EINVAL, "null output");
+  CTX.refresh_timers();
   *out = CTX.tm;
   return 0;
   API_END(ctx)

@@ -160,13 +160,16 @@ def trimer_melt(n_mol=200, rho=0.27, rc=2.5, skin=0.4, dt=0.0025, kT=1.0, gamma=
     the topology manager spawns ML-MA-MA / MA-MA-ML angles for registered type triples."""
     rng = np.random.default_rng(seed)
     n = 3 * n_mol
-    L = (n / rho) ** (1.0 / 3.0)
+    # trimers lie along x on an orthorhombic lattice so that no two beads overlap at t=0:
+    # cell (3.2, 1.86, 1.86) * s leaves a 1.26 end-to-end gap along x (reactive MA ends face each other)
     k = int(np.ceil(n_mol ** (1.0 / 3.0)))
-    a = L / k
+    cell = np.array([3.2, 1.86, 1.86])
+    cell *= ((3.0 / rho) / cell.prod()) ** (1.0 / 3.0)
+    box = (k * cell).tolist()
     g = np.arange(k)
     cx, cy, cz = np.meshgrid(g, g, g, indexing="ij")
-    centres = (np.stack([cx.ravel(), cy.ravel(), cz.ravel()], 1)[:n_mol] + 0.5) * a
-    dirs = rng.standard_normal((n_mol, 3))
+    centres = (np.stack([cx.ravel(), cy.ravel(), cz.ravel()], 1)[:n_mol] + 0.5) * cell
+    dirs = np.array([1.0, 0.0, 0.0]) + rng.uniform(-0.05, 0.05, (n_mol, 3))
     dirs /= np.linalg.norm(dirs, axis=1)[:, None]
     pos = np.empty((n_mol, 3, 3))
     pos[:, 1] = centres
@@ -181,7 +184,7 @@ def trimer_melt(n_mol=200, rho=0.27, rc=2.5, skin=0.4, dt=0.0025, kT=1.0, gamma=
     angles = np.stack([b0, b0 + 1, b0 + 2], 1)
     excl = np.concatenate([bonds, np.stack([b0, b0 + 2], 1)])
     mass = np.ones(n)
-    spec = dict(name="trimer_melt", n=n, box=[L] * 3, rc=rc, skin=skin, dt=dt, ids=ids, types=types, pos=pos,
+    spec = dict(name="trimer_melt", n=n, box=box, rc=rc, skin=skin, dt=dt, ids=ids, types=types, pos=pos,
                 vel=_maxwell(rng, n, kT, mass), mass=mass, state=np.zeros(n, np.int32),
                 res_id=(np.arange(n) // 3 + 1).astype(np.int32),
                 lj=[(MA, MA, 1.0, 1.0, rc), (MA, ML, 1.0, 1.0, rc), (ML, ML, 1.0, 1.0, rc)],

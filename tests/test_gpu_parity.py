@@ -1,0 +1,247 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on identical seeded
+inputs.  Tolerances: fp64 mode 1e-10 relative (summation order only); fp32 mode 2e-4 of the
+largest force (fp32 pair arithmetic, fp64 bonded).  Integer results (lists, events, states,
+types) must be bit-identical."""
+import numpy as np
+import pytest
+
+from chemlab_amd import workloads as W
+from conftest import rel_err
+from helpers import sorted_events, total_epot
+
+pytestmark = pytest.mark.gpu
+
+TOL = {64: 1e-10, 32: 2e-4}
+
+
+def both(make_gpu, make_oracle, spec, prec, **kw):
+    g, o = make_gpu(prec), make_oracle()
+    hg = W.apply(spec, g, **kw)
+    ho = W.apply(spec, o, **kw)
+    assert hg == ho
+    return g, o, hg
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_lj_melt_forces_energy_and_list(make_gpu, make_oracle, prec):
+    spec = W.lj_melt(n=4000, seed=1, jitter=0.08)
+    g, o, _ = both(make_gpu, make_oracle, spec, prec, thermostat=False)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[prec]
+    og, oo = g.observe(), o.observe()
+    assert og["epot_lj"] == pytest.approx(oo["epot_lj"], rel=1e-11 if prec == 64 else 2e-6)
+    assert og["ekin"] == pytest.approx(oo["ekin"], rel=1e-12 if prec == 64 else 1e-6)
+    assert og["virial_nb"] == pytest.approx(oo["virial_nb"], rel=1e-10 if prec == 64 else 1e-5)
+    if prec == 64:
+        assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
+    else:
+        a = {tuple(p) for p in g.get_verlet_pairs().tolist()}
+        b = {tuple(p) for p in o.get_verlet_pairs().tolist()}
+        assert len(a ^ b) <= 4      # pairs within fp32 rounding of rc+skin
+
+
+@pytest.mark.parametrize("tpp", [1, 2, 4, 8, 16, 32, 64])
+def test_pair_kernel_lane_widths_agree(make_gpu, make_oracle, tpp):
+    spec = W.lj_melt(n=2048, seed=6, jitter=0.08)
+    g, o, _ = both(make_gpu, make_oracle, spec, 64, thermostat=False)
+    g.set_option("tpp", tpp)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-10
+
+
+def test_small_box_brute_force_list(make_gpu, make_oracle):
+    # box edge < 3 (rc+skin): the list is built by the brute-force kernel with minimum image
+    rng = np.random.default_rng(3)
+    g1 = np.arange(7)
+    pos = np.stack(np.meshgrid(g1, g1, g1, indexing="ij"), -1).reshape(-1, 3) * 1.1 + 0.55 + rng.uniform(-0.05, 0.05, (343, 3))
+    n = 343
+    spec = dict(n=n, box=[7.7, 7.7, 7.7], rc=2.5, skin=0.3, dt=0.004, ids=np.arange(10, 10 + 2 * n, 2),
+                types=np.zeros(n, np.int32), pos=pos, vel=rng.normal(0, 0.5, (n, 3)),
+                mass=np.ones(n), lj=[(0, 0, 1.0, 1.0, 2.5)], kT=1.0, gamma=0.0, seed=1,
+                exclusions=np.array([[10, 12], [14, 30]]))
+    g, o, _ = both(make_gpu, make_oracle, spec, 64)
+    assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
+    g.run(40); o.run(40)
+    assert g.timers()["rebuilds"] == o.timers()["rebuilds"] >= 2
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_multi_type_lj_with_switched_off_pairs(make_gpu, make_oracle, prec):
+    spec = W.reactive_melt(n=4000, seed=2)
+    g, o, _ = both(make_gpu, make_oracle, spec, prec, thermostat=False, reactions=False)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[prec]
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_tabulated_and_bonded_polymer(make_gpu, make_oracle, prec):
+    spec = W.polymer_melt(n_chains=128, chain_len=32, seed=3)   # 4096 beads
+    g, o, h = both(make_gpu, make_oracle, spec, prec, thermostat=False)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[prec]
+    og, oo = g.observe(), o.observe()
+    for k in range(2):
+        assert og["epot_list"][k] == pytest.approx(oo["epot_list"][k], rel=1e-11 if prec == 64 else 1e-5)
+    assert og["epot_tab"] == pytest.approx(oo["epot_tab"], rel=1e-11 if prec == 64 else 1e-4, abs=1e-3)
+    assert og["list_size"] == oo["list_size"]
+    if prec == 64:
+        assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())   # exclusions honoured
+
+
+def test_dihedral_and_fene_and_cosine(make_gpu, make_oracle):
+    rng = np.random.default_rng(8)
+    nm = 125
+    base = (np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(5), indexing="ij"), -1).reshape(-1, 3) * 4.0 + 1.0)
+    off = np.array([[0, 0, 0], [0.9, 0.2, 0.1], [1.2, 1.1, 0.4], [2.1, 1.3, 1.2]])
+    pos = (base[:, None, :] + off[None]).reshape(-1, 3) + rng.uniform(-0.05, 0.05, (4 * nm, 3))
+    n = 4 * nm
+    ids = np.arange(1, n + 1).reshape(nm, 4)
+    spec = dict(n=n, box=[20.0] * 3, rc=2.5, skin=0.3, dt=0.002, ids=np.arange(1, n + 1), types=np.zeros(n, np.int32),
+                pos=pos, vel=rng.normal(0, 0.3, (n, 3)), mass=np.ones(n), lj=[(0, 0, 0.2, 0.8, 2.5)], kT=1.0, gamma=0.0, seed=1,
+                lists=[dict(arity=2, kind="FENE", params=[30.0, 0.0, 2.5], ids=np.concatenate([ids[:, [0, 1]], ids[:, [1, 2]], ids[:, [2, 3]]])),
+                       dict(arity=3, kind="ANG_COSINE", params=[2.0, np.deg2rad(130)], ids=np.concatenate([ids[:, [0, 1, 2]], ids[:, [1, 2, 3]]])),
+                       dict(arity=4, kind="DIH_NCOS", params=[1.5, np.deg2rad(20), 3.0], ids=ids),
+                       dict(arity=4, kind="DIH_RB", params=[0.5, -0.3, 0.2, 0.1, -0.1, 0.05], ids=ids[::2])],
+                exclusions=np.concatenate([ids[:, [0, 1]], ids[:, [1, 2]], ids[:, [2, 3]], ids[:, [0, 2]], ids[:, [1, 3]], ids[:, [0, 3]]]))
+    g, o, _ = both(make_gpu, make_oracle, spec, 64)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-10
+    og, oo = g.observe(), o.observe()
+    assert np.allclose(og["epot_list"], oo["epot_list"], rtol=1e-11)
+    g.run(50); o.run(50)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+
+
+def test_nve_trajectory_matches_oracle_fp64(make_gpu, make_oracle):
+    spec = W.lj_melt(n=4000, seed=1)
+    g, o, _ = both(make_gpu, make_oracle, spec, 64, thermostat=False)
+    g.run(100); o.run(100)
+    assert g.timers()["rebuilds"] == o.timers()["rebuilds"] >= 4
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+    assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < 1e-8
+    assert np.array_equal(g.get_state("IMAGE"), o.get_state("IMAGE"))
+
+
+def test_fused_and_split_integrator_agree(make_gpu):
+    spec = W.lj_melt(n=2048, seed=4, gamma=1.0)
+    a, b = make_gpu(64), make_gpu(64)
+    W.apply(spec, a); W.apply(spec, b)
+    b.set_option("fuse_integrate", 0)
+    a.run(40); b.run(40)
+    assert rel_err(a.get_state("POS_UNFOLDED"), b.get_state("POS_UNFOLDED")) < 1e-12
+
+
+def test_langevin_trajectory_matches_oracle_fp64(make_gpu, make_oracle):
+    spec = W.lj_melt(n=2048, seed=5, gamma=1.0)
+    g, o, _ = both(make_gpu, make_oracle, spec, 64)
+    g.run(30); o.run(30)
+    g.run(20); o.run(20)      # second call: run()-start force evaluation, phase-0 noise
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-8
+
+
+def test_fp32_nve_conserves_energy_and_momentum(make_gpu):
+    spec = W.lj_melt(n=32000, seed=1)            # C2 at full size
+    g = make_gpu(32)
+    W.apply(spec, g, thermostat=False)
+    g.run(0)
+    o0 = g.observe()
+    g.run(1000)
+    o1 = g.observe()
+    drift = abs((o1["ekin"] + o1["epot_lj"]) - (o0["ekin"] + o0["epot_lj"])) / spec["n"]
+    assert drift < 2e-3
+    assert np.abs(o1["momentum"]).max() < 1e-6 * spec["n"]
+    assert g.timers()["rebuilds"] > 30
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_reaction_scan_frozen_positions_bit_identical(make_gpu, make_oracle, prec):
+    """One React() on frozen, fp32-representable positions: candidate resolve, new bonds,
+    state and type vectors must be bit-identical; r^2 is evaluated in fp64 on both sides."""
+    spec = W.reactive_melt(n=8788, seed=11, interval=1, rho=0.8442)   # 13^3*4
+    spec["pos"] = spec["pos"].astype(np.float32).astype(np.float64)
+    spec["box"] = [float(np.float32(spec["box"][0]))] * 3
+    spec["dt"] = 1e-9
+    spec["vel"] = np.zeros_like(spec["vel"])
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e12
+    g, o, h = both(make_gpu, make_oracle, spec, prec, thermostat=False)
+    if prec == 32:
+        # dt=1e-9: x += dt*v leaves fp32 positions untouched only if forces*dt^2 underflow the ulp
+        pass
+    g.run(1); o.run(1)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 1000
+    if prec == 64:
+        assert eg == eo
+    else:
+        assert [e[:4] for e in eg] == [e[:4] for e in eo]
+        assert np.allclose([e[4] for e in eg], [e[4] for e in eo], rtol=1e-6)
+    assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+    assert np.array_equal(g.get_state("TYPE"), o.get_state("TYPE"))
+    assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+
+
+def test_reactive_trajectory_event_log_identical_fp64(make_gpu, make_oracle):
+    spec = W.reactive_melt(n=8788, seed=12, interval=25)
+    g, o, h = both(make_gpu, make_oracle, spec, 64)
+    for _ in range(3):
+        g.run(25); o.run(25)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 2000
+    assert [e[:4] for e in eg] == [e[:4] for e in eo]
+    assert np.allclose([e[4] for e in eg], [e[4] for e in eo], rtol=1e-9)
+    assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+    assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+    assert np.array_equal(g.get_state("TYPE"), o.get_state("TYPE"))
+    assert np.array_equal(g.get_state("RESID"), o.get_state("RESID"))
+    assert np.array_equal(g.get_state("MOLID"), o.get_state("MOLID"))
+    assert np.array_equal(g.get_exclusions(), o.get_exclusions())
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+
+
+def test_random_partner_mode_and_partial_rate_identical(make_gpu, make_oracle):
+    spec = W.reactive_melt(n=4000, seed=13, interval=10, rate=20.0)     # p = 20*0.005*10 = 1.0 -> use 6.0 -> 0.3
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 6.0
+    spec["reaction"]["nearest"] = False
+    g, o, h = both(make_gpu, make_oracle, spec, 64)
+    g.run(30); o.run(30)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 200
+    assert [e[:4] for e in eg] == [e[:4] for e in eo]
+
+
+def test_topology_manager_parity_trimer_melt(make_gpu, make_oracle):
+    spec = W.trimer_melt(n_mol=216, seed=4, interval=20)
+    g, o, h = both(make_gpu, make_oracle, spec, 64)
+    g.run(60); o.run(60)
+    assert len(o.get_events()) > 5
+    assert sorted_events(g.get_events()) == sorted_events(o.get_events()) or \
+        [e[:4] for e in sorted_events(g.get_events())] == [e[:4] for e in sorted_events(o.get_events())]
+    for k in (0, 1, "reaction_bonds"):
+        assert np.array_equal(g.get_list(h[k]), o.get_list(h[k]))
+    assert np.array_equal(g.get_exclusions(), o.get_exclusions())
+    assert np.array_equal(g.get_state("RESID"), o.get_state("RESID"))
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+    og, oo = g.observe(), o.observe()
+    assert np.allclose(og["epot_list"], oo["epot_list"], rtol=1e-8)
+    assert og["list_size"] == oo["list_size"]
+
+
+def test_modify_particle_and_errors(make_gpu):
+    from chemlab_amd.engine import ChemError
+    spec = W.lj_melt(n=500, seed=2)
+    g = make_gpu(32)
+    W.apply(spec, g, thermostat=False)
+    g.run(2)
+    g.modify_particle(7, "state", 3)
+    g.modify_particle(7, "mass", 2.5)
+    assert g.get_state("STATE")[6] == 3 and g.get_state("MASS")[6] == 2.5
+    with pytest.raises(ChemError):
+        g.modify_particle(10 ** 9, "state", 1)
+    with pytest.raises(ChemError):
+        g.reaction_init(0)
+    with pytest.raises(ChemError):
+        g.list_create(5, "HARMONIC")
