@@ -35,6 +35,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=8, help="oracle steps for the cpu_baseline leg (0 = skip)")
     p.add_argument("--tpp", type=int, default=0)
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--verbose", action="store_true", help="timers to stderr")
     return p.parse_args()
 
 
@@ -114,6 +115,8 @@ def main():
                                frac=achieved / HBM_PEAK, traffic=None, avg_launch_us=avg_s * 1e6, launches=launches,
                                mean_neighbours=nb, algorithmic_bytes_per_particle=bytes_per_particle,
                                whole_step_frac=a.n * (bytes_per_particle + 80.0) * steps_per_s / HBM_PEAK)
+    if a.verbose:
+        print("timers:", json.dumps(eng.timers()), file=sys.stderr)
     if a.cpu_steps > 0:
         out["cpu_baseline"] = cpu_baseline(spec, a.cpu_steps)
     print(json.dumps(out))

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <memory>
+#include <tuple>
 
 #include "chem_host.hpp"
 #include "md_kernels.hpp"
@@ -64,6 +65,7 @@ struct Ctx {
   int interval = 0, nearest = 1; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
   std::vector<chem_event> events;
+  size_t events_sorted = 0;  // prefix of `events` already in canonical order
   int64_t step = 0;
   bool resort = true;
   bool geom_dirty = true, particles_dirty = true, pair_dirty = true, bonded_dirty = true, excl_dirty = true, labels_dirty = true;
@@ -71,6 +73,7 @@ struct Ctx {
   int opt_tpp = 0;          // 0 = automatic
   int opt_time_pair = 0;    // HIP-event timing of every pair-force launch
   int opt_fuse = 1;         // fused integrate2+integrate1
+  int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
   chem_timers tm{};
   virtual ~Ctx() {}
   virtual void run(int64_t nsteps) = 0;
@@ -84,6 +87,8 @@ struct Ctx {
 
 template <typename R> struct CtxT : Ctx {
   using V4 = Vec4<R>;
+  int tile_cap = 0;       // LDS slots of one staged tile (dynamic LDS)
+  size_t tile_lds_bytes() const { return (size_t)(tile_cap + 2) * sizeof(V4) + 16; }
   hipStream_t stream = nullptr;
   int n = 0;
   DBuf<V4> x4, v4, f4, x4o, v4o, tab;
@@ -91,11 +96,15 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int4> img4, img4o;
   DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
   DBuf<int> nlist, nn;
+  DBuf<unsigned short> nl16;
   int S = 0;
+  bool use_tiles = false, want32 = true;
+  int ntiles = 0;
   DBuf<int> excl_start, excl_list; int has_excl = 0;
   DBuf<int> bstart; DBuf<BondedEntry> bent; DBuf<BondedParam> bpar; int64_t nbent = 0;
   DBuf<PairCore<R>> pcore; DBuf<PairExt<R>> pext;
   DBuf<DevCtl> ctl;
+  DBuf<unsigned long long> blockmax;
   DBuf<double> eout, ekout, elist;
   // reactions
   DBuf<Candidate> cand, evout; int cand_cap = 0;
@@ -138,10 +147,38 @@ template <typename R> struct CtxT : Ctx {
     int cap = nl_capacity_user > 0 ? nl_capacity_user : (int)(expect * 1.6 + 48);
     cap = std::min(cap, std::max(n - 1, 1));
     S = (cap + 15) / 16 * 16;
-    nlist.free(); nlist.alloc((size_t)n * S);
-    tm.nlist_capacity = S;
+    use_tiles = opt_tiles && box.nc[0] >= HX + 2 && box.nc[1] >= HY + 2 && box.nc[2] >= HZ + 2;
+    if (use_tiles) {
+      // LDS capacity from the mean stencil occupancy (+12 % for density fluctuations), in 256-slot steps
+      const double per_cell = (double)n / box.ncell;
+      const int need = (int)(SX * SY * SZ * per_cell * 1.12) + 64;
+      tile_cap = std::max(1024, (need + 255) / 256 * 256);
+      const size_t max_lds = 150 * 1024;
+      if (tile_lds_bytes() > max_lds) use_tiles = false;   // cells too crowded: per-cell kernels
+      else set_tile_lds_attr();
+    }
+    ntiles = use_tiles ? ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY) * ((box.nc[2] + HZ - 1) / HZ) : 0;
+    alloc_lists();
     HIPCHK(hipStreamSynchronize(stream));
     geom_dirty = false; resort = true;
+  }
+
+  void set_tile_lds_attr() {
+    const int bytes = (int)tile_lds_bytes();
+#define SETA(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
+    SETA(k_nlist_tiles<R>);
+    SETA((k_pair_tiles<R, 1, false>)); SETA((k_pair_tiles<R, 2, false>)); SETA((k_pair_tiles<R, 4, false>));
+    SETA((k_pair_tiles<R, 8, false>)); SETA((k_pair_tiles<R, 16, false>));
+    SETA((k_pair_tiles<R, 1, true>)); SETA((k_pair_tiles<R, 2, true>)); SETA((k_pair_tiles<R, 4, true>));
+    SETA((k_pair_tiles<R, 8, true>)); SETA((k_pair_tiles<R, 16, true>));
+#undef SETA
+  }
+
+  void alloc_lists() {
+    nlist.free(); nl16.free();
+    if (!use_tiles || want32) nlist.alloc((size_t)n * S);
+    if (use_tiles) nl16.alloc((size_t)n * S);
+    tm.nlist_capacity = S;
   }
 
   void upload_particles() {
@@ -161,6 +198,8 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipMemsetAsync(nn.p, 0, sizeof(int) * n, stream));
     ctl.alloc(1);
     HIPCHK(hipMemsetAsync(ctl.p, 0, sizeof(DevCtl), stream));
+    blockmax.alloc(cdiv(n, 256));
+    HIPCHK(hipMemsetAsync(blockmax.p, 0, sizeof(unsigned long long) * cdiv(n, 256), stream));
     eout.alloc(3 * (size_t)cdiv((long long)n * 64, 256) + 8);
     ekout.alloc(4 * (size_t)cdiv(n, 256) + 8);
     elist.alloc(CHEM_MAX_LISTS);
@@ -242,18 +281,23 @@ template <typename R> struct CtxT : Ctx {
   }
 
   // ---- rebuild chain (every kernel early-exits unless ctl->need_rebuild) ---------------
+  // Grids are capped ("persistent" grid-stride kernels) so that the early-exit launches of the
+  // steps that do not rebuild cost ~2 us each instead of a full-size dispatch.
   void launch_rebuild_chain() {
-    const int nb = cdiv(n, 256);
+    const int nb = std::min(cdiv(n, 256), 2048);
     DevCtl* c = ctl.p;
     hipLaunchKernelGGL(k_bin<R>, dim3(nb), dim3(256), 0, stream, n, x4.p, img4.p, box, cell_cnt.p, cell_of.p, slot_of.p, c);
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream, box.ncell, cell_cnt.p, cell_start.p, c);
     hipLaunchKernelGGL(k_place, dim3(nb), dim3(256), 0, stream, n, cell_of.p, slot_of.p, cell_start.p, perm.p, c);
-    hipLaunchKernelGGL(k_sort_cells, dim3(cdiv(box.ncell, 256)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p, tag.p, c);
-    hipLaunchKernelGGL(k_gather<R>, dim3(nb), dim3(256), 0, stream, n, perm.p, x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
+    hipLaunchKernelGGL(k_sort_gather<R>, dim3(std::min(cdiv(box.ncell, 4), 2048)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p,
+                       x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
     hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, n, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, c);
     const R rl2 = (R)((rc + skin) * (rc + skin));
-    if (box.nc[0] > 0)
-      hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(box.ncell), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
+    if (use_tiles)
+      hipLaunchKernelGGL((k_nlist_tiles<R>), dim3(std::min(ntiles, 1280)), dim3(256), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, cell_start.p, box, rl2,
+                         excl_start.p, excl_list.p, has_excl, nl16.p, S, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
+    else if (box.nc[0] > 0)
+      hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
                          excl_start.p, excl_list.p, has_excl, nlist.p, nn.p, S, c);
     else
       hipLaunchKernelGGL(k_nlist_brute<R>, dim3(cdiv(n, 4)), dim3(256), 0, stream, n, x4.p, tag.p, box, rl2, excl_start.p,
@@ -261,7 +305,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void decide_and_rebuild() {
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1), 0, stream, ctl.p, 0.5 * skin);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin);
     launch_rebuild_chain();
   }
 
@@ -285,13 +329,12 @@ template <typename R> struct CtxT : Ctx {
       set_ctl_field(&DevCtl::force_rebuild, 1);
       decide_and_rebuild();
       DevCtl h = read_ctl();
-      if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil holds " + std::to_string(h.stage_overflow) + " particles, LDS tile capacity 1536: density too high for cell edge rc+skin");
+      if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil holds " + std::to_string(h.stage_overflow) + " particles, LDS tile capacity " + std::to_string(use_tiles ? tile_cap : 1536) + " (density fluctuation beyond the 12 % margin)");
       if (!h.nl_overflow) { resort = false; tm.rebuild_wall_s += now_s() - t0; return; }
       int newS = ((int)(h.nl_overflow * 1.25) + 31) / 16 * 16;
       if (nl_capacity_user > 0) throw ChemError(CHEM_ENOSPC, "neighbour capacity " + std::to_string(S) + " too small, need " + std::to_string(h.nl_overflow));
       S = std::min(newS, std::max((n + 15) / 16 * 16, 16));
-      nlist.free(); nlist.alloc((size_t)n * S);
-      tm.nlist_capacity = S;
+      alloc_lists();
       set_ctl_field(&DevCtl::nl_overflow, 0);
     }
     throw ChemError(CHEM_ENOSPC, "neighbour list capacity could not be satisfied");
@@ -299,13 +342,21 @@ template <typename R> struct CtxT : Ctx {
 
   // ---- forces -------------------------------------------------------------------------
   int pick_tpp() const {
-    if (opt_tpp > 0) return opt_tpp;
-    return n >= 400000 ? 8 : 16;
+    if (opt_tpp > 0) return use_tiles ? std::min(opt_tpp, 16) : opt_tpp;
+    if (use_tiles) return 4;
+    return n >= 100000 ? 4 : (n >= 8000 ? 8 : 16);
   }
 
-  template <bool ENERGY> void launch_pair(V4* fdst, int tpp) {
-    const int nb = cdiv((long long)n * tpp, 256);
+  template <bool ENERGY> int launch_pair(V4* fdst, int tpp) {
     const double hs = 0.5 * skin;
+    if (use_tiles) {
+#define LT(T) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY>), dim3(ntiles), dim3(256), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, fdst, cell_start.p, \
+                                 nl16.p, nn.p, S, box, pcore.p, pext.p, ntypes, tab.p, eout.p, hs, ctl.p)
+      switch (tpp) { case 1: LT(1); break; case 2: LT(2); break; case 4: LT(4); break; case 8: LT(8); break; default: LT(16); break; }
+#undef LT
+      return ntiles;
+    }
+    const int nb = cdiv((long long)n * tpp, 256);
 #define LP(T) hipLaunchKernelGGL((k_pair_force<R, T, ENERGY>), dim3(nb), dim3(256), 0, stream, n, x4.p, fdst, nlist.p, nn.p, S, box, \
                                  pcore.p, pext.p, ntypes, tab.p, eout.p, hs, ctl.p)
     switch (tpp) {
@@ -313,6 +364,7 @@ template <typename R> struct CtxT : Ctx {
       case 16: LP(16); break; case 32: LP(32); break; default: LP(64); break;
     }
 #undef LP
+    return nb;
   }
 
   void compute_forces() {
@@ -336,11 +388,11 @@ template <typename R> struct CtxT : Ctx {
     const int nb = cdiv(n, 256);
     LangevinP<R> lp = lang_params(istep, phase);
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p);
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p);
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p);
   }
 
   void check_flags() {
@@ -390,6 +442,10 @@ template <typename R> struct CtxT : Ctx {
       for (size_t k = 0; k + 1 < ev_used; k += 2) { float t = 0; HIPCHK(hipEventElapsedTime(&t, ev[k], ev[k + 1])); ms += t; }
       tm.pair_kernel_ms = ms; tm.pair_kernel_launches = (int64_t)(ev_used / 2);
     }
+  }
+
+  void ensure_list32() {
+    if (use_tiles && !want32) { want32 = true; nlist.alloc((size_t)n * S); resort = true; }
   }
 
   // ---- reactions ----------------------------------------------------------------------
@@ -449,10 +505,14 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipStreamSynchronize(stream));
     std::vector<Candidate> hev;
     evout.download(hev, (size_t)nev, stream);
-    std::sort(hev.begin(), hev.end(), [](const Candidate& p, const Candidate& q) {
-      return std::make_pair(std::min(p.a, p.b), std::max(p.a, p.b)) < std::make_pair(std::min(q.a, q.b), std::max(q.a, q.b));
-    });
-    // host mirrors + topology
+    // Host mirrors + topology.  Only bond-forming events need the canonical order now (it fixes
+    // the order of the bond lists); the event log itself is put in canonical order lazily
+    // by chem_get_events.
+    auto ekey = [](const Candidate& p) { return ((uint64_t)(uint32_t)std::min(p.a, p.b) << 32) | (uint32_t)std::max(p.a, p.b); };
+    {
+      auto mid = std::partition(hev.begin(), hev.end(), [&](const Candidate& p) { return !reactions[p.r].is_virtual; });
+      std::sort(hev.begin(), mid, [&](const Candidate& p, const Candidate& q) { return ekey(p) < ekey(q); });
+    }
     std::vector<std::pair<int32_t, int32_t>> newbonds;
     bool types_changed = false;
     for (auto& e : hev) {
@@ -530,8 +590,7 @@ template <typename R> struct CtxT : Ctx {
     if (resort) rebuild_now();
     std::memset(out, 0, sizeof(*out));
     const int tpp = pick_tpp();
-    const int nb = cdiv((long long)n * tpp, 256);
-    launch_pair<true>(x4o.p, tpp);  // scratch force buffer: leaves f4 untouched
+    const int nb = launch_pair<true>(x4o.p, tpp);  // scratch force buffer: leaves f4 untouched
     HIPCHK(hipMemsetAsync(elist.p, 0, sizeof(double) * CHEM_MAX_LISTS, stream));
     if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, true>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n, x4.p, x4o.p, tag.p, rtag.p, bstart.p, bent.p,
@@ -551,6 +610,7 @@ template <typename R> struct CtxT : Ctx {
 
   int64_t verlet_pairs(int64_t* out, int64_t cap) override {
     flush_host_state();
+    ensure_list32();
     if (resort) rebuild_now();
     std::vector<int> hn, ht, hl;
     nn.download(hn, n, stream); tag.download(ht, n, stream); nlist.download(hl, (size_t)n * S, stream);
@@ -678,7 +738,7 @@ int chem_set_particles(chem_ctx* ctx, int64_t n, const int64_t* id, const int32_
   }
   if (!t.contiguous) for (int64_t k = 0; k < n; ++k) t.id2tag[t.id[k]] = (int32_t)k;
   c.particles_dirty = c.pair_dirty = c.bonded_dirty = c.excl_dirty = c.labels_dirty = true; c.resort = true;
-  c.step = 0; c.events.clear();
+  c.step = 0; c.events.clear(); c.events_sorted = 0;
   return 0;
   API_END(ctx)
 }
@@ -875,6 +935,13 @@ int64_t chem_get_events(chem_ctx* ctx, chem_event* out, int64_t cap) {
   const int64_t n = (int64_t)CTX.events.size();
   if (!out) return n;
   REQUIRE(cap >= n, CHEM_ENOSPC, "get_events: capacity");
+  if (CTX.events_sorted < CTX.events.size()) {   // canonical order: (step, min id, max id)
+    std::sort(CTX.events.begin() + CTX.events_sorted, CTX.events.end(), [](const chem_event& p, const chem_event& q) {
+      return std::make_tuple(p.step, std::min(p.id_a, p.id_b), std::max(p.id_a, p.id_b)) <
+             std::make_tuple(q.step, std::min(q.id_a, q.id_b), std::max(q.id_a, q.id_b));
+    });
+    CTX.events_sorted = CTX.events.size();
+  }
   std::copy(CTX.events.begin(), CTX.events.end(), out);
   return n;
   API_END(ctx)
@@ -914,6 +981,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   if (k == "tpp") { const int v = (int)value; REQUIRE(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64, CHEM_EINVAL, "tpp must be a power of two <= 64"); CTX.opt_tpp = v; }
   else if (k == "time_pair_kernel") CTX.opt_time_pair = value != 0;
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
+  else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else throw ChemError(CHEM_EINVAL, "unknown option " + k);
   return 0;
   API_END(ctx)

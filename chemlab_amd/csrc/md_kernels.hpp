@@ -30,6 +30,8 @@ __device__ __forceinline__ double rint_r(double x) { return rint(x); }
 __device__ __forceinline__ float sqrt_r(float x) { return sqrtf(x); }
 __device__ __forceinline__ double sqrt_r(double x) { return sqrt(x); }
 __device__ __forceinline__ float floor_r(float x) { return floorf(x); }
+__device__ __forceinline__ float rcp_r(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp, fp32 production mode
+__device__ __forceinline__ double rcp_r(double x) { return 1.0 / x; }
 __device__ __forceinline__ double floor_r(double x) { return floor(x); }
 
 constexpr int kMaxTypes = CHEM_MAX_TYPES;
@@ -103,7 +105,7 @@ __device__ __forceinline__ void langevin_force(const LangevinP<R>& lp, int tag, 
 template <typename R, int MODE, bool LANG, bool STOREF>
 __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
-                                                    R dt, LangevinP<R> lp, DevCtl* ctl) {
+                                                    R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   R d2 = 0;
   if (i < n) {
@@ -125,22 +127,38 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
     v4[i] = v;
   }
   if (MODE & 2) {
-    // wave max via DPP-style shuffles, then one atomic per wave
+    // max |dx|^2 of the block -> blockmax[blockIdx.x]; folded by k_rebuild_decide (no contended atomics)
+    __shared__ unsigned long long wm[4];
     for (int o = 32; o > 0; o >>= 1) { R t = __shfl_xor(d2, o); d2 = t > d2 ? t : d2; }
-    if (lane_id() == 0) atomicMax(&ctl->step_max2_bits, real_bits(d2));
+    if (lane_id() == 0) wm[threadIdx.x >> 6] = real_bits(d2);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = wm[0];
+      for (int k = 1; k < 4; ++k) m = wm[k] > m ? wm[k] : m;
+      blockmax[blockIdx.x] = m;
+    }
   }
 }
 
-// one thread: fold the step's max displacement into the accumulated distance and decide
+// one block: fold the step's per-block max displacement into the accumulated distance and
+// decide whether the Verlet list must be rebuilt (VelocityVerlet::run)
 template <typename R>
-__global__ void k_rebuild_decide(DevCtl* ctl, double half_skin) {
-  double m2 = sizeof(R) == 4 ? bits_real_f(ctl->step_max2_bits) : bits_real_d(ctl->step_max2_bits);
-  ctl->step_max2_bits = 0ull;
-  double acc = ctl->acc_maxdist + sqrt(m2);
-  int need = (acc > half_skin) || ctl->force_rebuild;
-  if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
-  ctl->acc_maxdist = acc;
-  ctl->need_rebuild = need;
+__global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned long long* __restrict__ blockmax, int nblk, double half_skin) {
+  unsigned long long m = 0;
+  for (int k = threadIdx.x; k < nblk; k += 1024) { unsigned long long b = blockmax[k]; blockmax[k] = 0ull; m = b > m ? b : m; }
+  for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+  __shared__ unsigned long long wm[16];
+  if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) m = wm[k] > m ? wm[k] : m;
+    const double m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
+    double acc = ctl->acc_maxdist + sqrt(m2);
+    const int need = (acc > half_skin) || ctl->force_rebuild;
+    if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
+    ctl->acc_maxdist = acc;
+    ctl->need_rebuild = need;
+  }
 }
 
 // =======================================================================================
@@ -151,91 +169,102 @@ __global__ __launch_bounds__(256) void k_bin(int n, Vec4<R>* __restrict__ x4, in
                                              int* __restrict__ cell_cnt, int* __restrict__ cell_of,
                                              int* __restrict__ slot_of, const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Vec4<R> x = x4[i];
-  int4 im = img4[i];
-  R* p = &x.x; int* ip = &im.x;
-  int c[3];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    Vec4<R> x = x4[i];
+    int4 im = img4[i];
+    R* p = &x.x; int* ip = &im.x;
+    int c[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    R s = floor_r(p[d] * box.invL[d]);
-    if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
-    if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
-    if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
-    int cc = (int)(p[d] * box.cell_inv[d]);
-    int ncd = box.nc[d] > 0 ? box.nc[d] : 1;
-    cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
-    c[d] = cc;
+    for (int d = 0; d < 3; ++d) {
+      R s = floor_r(p[d] * box.invL[d]);
+      if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
+      if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
+      if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
+      int cc = (int)(p[d] * box.cell_inv[d]);
+      int ncd = box.nc[d] > 0 ? box.nc[d] : 1;
+      cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
+      c[d] = cc;
+    }
+    x4[i] = x; img4[i] = im;
+    int cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
+    cell_of[i] = cid;
+    slot_of[i] = atomicAdd(&cell_cnt[cid], 1);
   }
-  x4[i] = x; img4[i] = im;
-  int cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
-  cell_of[i] = cid;
-  slot_of[i] = atomicAdd(&cell_cnt[cid], 1);
 }
 
-// single-block exclusive scan of cell counts -> cell_start[0..ncell]; zeroes cell_cnt for next time
+
+// single-block exclusive scan of cell counts -> cell_start[0..ncell]; zeroes cell_cnt for next time.
+// 4096-element tiles, coalesced, thread-local 4-scan + wave shuffle scan + 16 wave partials.
 __global__ __launch_bounds__(1024) void k_scan_cells(int ncell, int* __restrict__ cell_cnt, int* __restrict__ cell_start,
                                                      const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
   __shared__ int wsum[16];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < ncell; base += 1024) {
-    int i = base + threadIdx.x;
-    int v = i < ncell ? cell_cnt[i] : 0;
-    if (i < ncell) cell_cnt[i] = 0;
-    int incl = v;
+  const int w = threadIdx.x >> 6;
+  for (int base = 0; base < ncell; base += 4096) {
+    const int i0 = base + threadIdx.x * 4;
+    int v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u] = (i0 + u < ncell) ? cell_cnt[i0 + u] : 0; if (i0 + u < ncell) cell_cnt[i0 + u] = 0; }
+    const int sum = v[0] + v[1] + v[2] + v[3];
+    int incl = sum;
     for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane_id() >= o) incl += t; }
-    int w = threadIdx.x >> 6;
     if (lane_id() == 63) wsum[w] = incl;
     __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < w; ++k) woff += wsum[k];
-    int tot = 0;
-    for (int k = 0; k < 16; ++k) tot += wsum[k];
-    int c0 = carry;
-    if (i < ncell) cell_start[i] = c0 + woff + incl - v;
+    int woff = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) woff += wsum[k]; tot += wsum[k]; }
+    int run = carry_s + woff + incl - sum;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { if (i0 + u < ncell) cell_start[i0 + u] = run; run += v[u]; }
     __syncthreads();
-    if (threadIdx.x == 0) carry = c0 + tot;
+    if (threadIdx.x == 0) carry_s += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) cell_start[ncell] = carry;
+  if (threadIdx.x == 0) cell_start[ncell] = carry_s;
 }
 
 __global__ __launch_bounds__(256) void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of,
                                                const int* __restrict__ cell_start, int* __restrict__ perm, const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) perm[cell_start[cell_of[i]] + slot_of[i]] = i;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    perm[cell_start[cell_of[i]] + slot_of[i]] = i;
 }
 
-// canonical order inside a cell: ascending tag (makes the whole pipeline run-to-run deterministic)
-__global__ __launch_bounds__(256) void k_sort_cells(int ncell, const int* __restrict__ cell_start, int* __restrict__ perm,
-                                                    const int* __restrict__ tag, const DevCtl* ctl) {
-  if (!ctl->need_rebuild) return;
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncell) return;
-  int s = cell_start[c], e = cell_start[c + 1];
-  for (int a = s + 1; a < e; ++a) {
-    int pa = perm[a], ta = tag[pa], b = a - 1;
-    while (b >= s) { int pb = perm[b]; if (tag[pb] <= ta) break; perm[b + 1] = pb; --b; }
-    perm[b + 1] = pa;
-  }
-}
-
+// One wave per cell: rank the members by tag (canonical order inside a cell => the whole pipeline
+// is run-to-run deterministic) and gather the particle arrays into cell-sorted order.
 template <typename R>
-__global__ __launch_bounds__(256) void k_gather(int n, const int* __restrict__ perm, const Vec4<R>* __restrict__ x4,
-                                                const Vec4<R>* __restrict__ v4,
-                                                const int* __restrict__ tag, const int4* __restrict__ img4,
-                                                Vec4<R>* __restrict__ x4o, Vec4<R>* __restrict__ v4o,
-                                                int* __restrict__ tago, int4* __restrict__ img4o, const DevCtl* ctl) {
+__global__ __launch_bounds__(256) void k_sort_gather(int ncell, const int* __restrict__ cell_start, const int* __restrict__ perm,
+                                                     const Vec4<R>* __restrict__ x4, const Vec4<R>* __restrict__ v4,
+                                                     const int* __restrict__ tag, const int4* __restrict__ img4,
+                                                     Vec4<R>* __restrict__ x4o, Vec4<R>* __restrict__ v4o,
+                                                     int* __restrict__ tago, int4* __restrict__ img4o, const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  int i = perm[k];
-  x4o[k] = x4[i]; v4o[k] = v4[i]; tago[k] = tag[i]; img4o[k] = img4[i];
+  const int l = lane_id();
+  const int nw = gridDim.x * (blockDim.x >> 6);
+  for (int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < ncell; c += nw) {
+    const int s = cell_start[c], cnt = cell_start[c + 1] - s;
+    if (cnt <= 64) {
+      int pi = 0, tg = 0x7fffffff;
+      if (l < cnt) { pi = perm[s + l]; tg = tag[pi]; }
+      int rank = 0;
+      for (int k = 0; k < cnt; ++k) { const int tk = __shfl(tg, k); rank += (tk < tg) ? 1 : 0; }
+      if (l < cnt) {
+        const int dst = s + rank;
+        x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+      }
+    } else {
+      // crowded cell: each lane ranks its members against all others through global memory
+      for (int a = l; a < cnt; a += 64) {
+        const int pi = perm[s + a], tg = tag[pi];
+        int rank = 0;
+        for (int k = 0; k < cnt; ++k) rank += (tag[perm[s + k]] < tg) ? 1 : 0;
+        const int dst = s + rank;
+        x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+      }
+    }
+  }
 }
 
 template <typename R>
@@ -245,10 +274,10 @@ __global__ __launch_bounds__(256) void k_copyback(int n, const Vec4<R>* __restri
                                                   int* __restrict__ tag, int4* __restrict__ img4,
                                                   int* __restrict__ rtag, const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  x4[k] = x4o[k]; v4[k] = v4o[k]; img4[k] = img4o[k];
-  int t = tago[k]; tag[k] = t; rtag[t] = k;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+    x4[k] = x4o[k]; v4[k] = v4o[k]; img4[k] = img4o[k];
+    int t = tago[k]; tag[k] = t; rtag[t] = k;
+  }
 }
 
 // =======================================================================================
@@ -258,6 +287,20 @@ __global__ __launch_bounds__(256) void k_copyback(int n, const Vec4<R>* __restri
 //     tests 64 staged candidates per instruction; __ballot + popcount compacts the hits into
 //     the particle's row with coalesced stores.
 // =======================================================================================
+__device__ __forceinline__ float idx_as_real(int i, float) { return __int_as_float(i); }
+__device__ __forceinline__ double idx_as_real(int i, double) { return __longlong_as_double((long long)i); }
+__device__ __forceinline__ int real_as_idx(float w) { return __float_as_int(w); }
+__device__ __forceinline__ int real_as_idx(double w) { return (int)__double_as_longlong(w); }
+
+// rows are padded with the particle's own index up to a multiple of 4 entries so that the
+// force kernel can read them as int4 (the self entry has r = 0 and is masked there)
+__device__ __forceinline__ void finish_row(int* row, int* nn, int p, int cnt, int S, int l, DevCtl* ctl) {
+  const int c = cnt < S ? cnt : S;
+  const int pad = (4 - (c & 3)) & 3;
+  if (l < pad) row[c + l] = p;
+  if (l == 0) { nn[p] = c; if (cnt > S) atomicMax(&ctl->nl_overflow, cnt); }
+}
+
 template <typename R, int CAP>
 __global__ __launch_bounds__(256) void k_nlist_cells(int n, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
                                                      const int* __restrict__ cell_start, Box<R> box, R rl2,
@@ -265,82 +308,80 @@ __global__ __launch_bounds__(256) void k_nlist_cells(int n, const Vec4<R>* __res
                                                      int has_excl, int* __restrict__ nlist, int* __restrict__ nn, int S,
                                                      DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  __shared__ Vec4<R> sx[CAP];
-  __shared__ int sidx[CAP];
+  __shared__ Vec4<R> sx[CAP];          // (x, y, z, bits of the global index), periodic shift applied
   __shared__ int seg_start[27], seg_cnt[27], seg_off[28];
   __shared__ R seg_shift[27][3];
-  const int c = blockIdx.x;
   const int nx = box.nc[0], ny = box.nc[1], nz = box.nc[2];
-  const int cx = c % nx, cy = (c / nx) % ny, cz = c / (nx * ny);
-  if (threadIdx.x < 27) {
-    int k = threadIdx.x;
-    int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
-    int ox = cx + dx, oy = cy + dy, oz = cz + dz;
-    R sh[3] = {0, 0, 0};
-    if (ox < 0) { ox += nx; sh[0] = -box.L[0]; } else if (ox >= nx) { ox -= nx; sh[0] = box.L[0]; }
-    if (oy < 0) { oy += ny; sh[1] = -box.L[1]; } else if (oy >= ny) { oy -= ny; sh[1] = box.L[1]; }
-    if (oz < 0) { oz += nz; sh[2] = -box.L[2]; } else if (oz >= nz) { oz -= nz; sh[2] = box.L[2]; }
-    int oc = (oz * ny + oy) * nx + ox;
-    seg_start[k] = cell_start[oc];
-    seg_cnt[k] = cell_start[oc + 1] - cell_start[oc];
-    seg_shift[k][0] = sh[0]; seg_shift[k][1] = sh[1]; seg_shift[k][2] = sh[2];
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int o = 0;
-    for (int k = 0; k < 27; ++k) { seg_off[k] = o; o += seg_cnt[k]; }
-    seg_off[27] = o;
-    if (o > CAP) atomicMax(&ctl->stage_overflow, o);
-  }
-  __syncthreads();
-  const int total = min(seg_off[27], CAP);
-  // stage: one wave per segment round-robin, coalesced 16/32-byte loads
   const int w = threadIdx.x >> 6, l = lane_id();
-  for (int k = w; k < 27; k += 4) {
-    const int s0 = seg_start[k], cnt = seg_cnt[k], o0 = seg_off[k];
-    const R sh0 = seg_shift[k][0], sh1 = seg_shift[k][1], sh2 = seg_shift[k][2];
-    for (int t = l; t < cnt; t += 64) {
-      int dst = o0 + t;
-      if (dst < CAP) {
-        Vec4<R> p = x4[s0 + t];
-        p.x += sh0; p.y += sh1; p.z += sh2;
-        sx[dst] = p; sidx[dst] = s0 + t;
-      }
+  for (int c = blockIdx.x; c < box.ncell; c += gridDim.x) {
+    const int cx = c % nx, cy = (c / nx) % ny, cz = c / (nx * ny);
+    __syncthreads();   // previous cell's tile fully consumed
+    if (threadIdx.x < 27) {
+      int k = threadIdx.x;
+      int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+      int ox = cx + dx, oy = cy + dy, oz = cz + dz;
+      R sh[3] = {0, 0, 0};
+      if (ox < 0) { ox += nx; sh[0] = -box.L[0]; } else if (ox >= nx) { ox -= nx; sh[0] = box.L[0]; }
+      if (oy < 0) { oy += ny; sh[1] = -box.L[1]; } else if (oy >= ny) { oy -= ny; sh[1] = box.L[1]; }
+      if (oz < 0) { oz += nz; sh[2] = -box.L[2]; } else if (oz >= nz) { oz -= nz; sh[2] = box.L[2]; }
+      int oc = (oz * ny + oy) * nx + ox;
+      seg_start[k] = cell_start[oc];
+      seg_cnt[k] = cell_start[oc + 1] - cell_start[oc];
+      seg_shift[k][0] = sh[0]; seg_shift[k][1] = sh[1]; seg_shift[k][2] = sh[2];
     }
-  }
-  __syncthreads();
-  const int hs = cell_start[c], he = cell_start[c + 1];
-  for (int p = hs + w; p < he; p += 4) {
-    const Vec4<R> xi = x4[p];
-    int e0 = 0, e1 = 0;
-    if (has_excl) { int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
-    int cnt = 0;
-    int* row = nlist + (size_t)p * S;
-    for (int s0 = 0; s0 < total; s0 += 64) {
-      const int s = s0 + l;
-      bool ok = s < total;
-      int j = -1;
-      if (ok) {
-        const Vec4<R> xj = sx[s];
-        j = sidx[s];
-        const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-        const R r2 = dx * dx + dy * dy + dz * dz;
-        ok = (r2 <= rl2) && (j != p);
-        if (ok && e1 > e0) {
-          const int tj = tag[j];
-          for (int e = e0; e < e1; ++e) if (excl_list[e] == tj) { ok = false; break; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int o = 0;
+      for (int k = 0; k < 27; ++k) { seg_off[k] = o; o += seg_cnt[k]; }
+      seg_off[27] = o;
+      if (o > CAP) atomicMax(&ctl->stage_overflow, o);
+    }
+    __syncthreads();
+    const int total = min(seg_off[27], CAP);
+    // stage: one wave per stencil cell round-robin, coalesced 16/32-byte loads
+    for (int k = w; k < 27; k += 4) {
+      const int s0 = seg_start[k], cnt = seg_cnt[k], o0 = seg_off[k];
+      const R sh0 = seg_shift[k][0], sh1 = seg_shift[k][1], sh2 = seg_shift[k][2];
+      for (int t = l; t < cnt; t += 64) {
+        const int dst = o0 + t;
+        if (dst < CAP) {
+          Vec4<R> p = x4[s0 + t];
+          p.x += sh0; p.y += sh1; p.z += sh2; p.w = idx_as_real(s0 + t, (R)0);
+          sx[dst] = p;
         }
       }
-      const unsigned long long m = __ballot(ok);
-      if (ok) {
-        const int pos = cnt + __popcll(m & lanemask_lt());
-        if (pos < S) row[pos] = j;
-      }
-      cnt += __popcll(m);
     }
-    if (l == 0) {
-      nn[p] = cnt < S ? cnt : S;
-      if (cnt > S) atomicMax(&ctl->nl_overflow, cnt);
+    __syncthreads();
+    const int hs = cell_start[c], he = cell_start[c + 1];
+    for (int p = hs + w; p < he; p += 4) {
+      const Vec4<R> xi = x4[p];
+      int e0 = 0, e1 = 0;
+      if (has_excl) { int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
+      int cnt = 0;
+      int* row = nlist + (size_t)p * S;
+      for (int s0 = 0; s0 < total; s0 += 64) {
+        const int s = s0 + l;
+        bool ok = s < total;
+        int j = -1;
+        if (ok) {
+          const Vec4<R> xj = sx[s];
+          j = real_as_idx(xj.w);
+          const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+          const R r2 = dx * dx + dy * dy + dz * dz;
+          ok = (r2 <= rl2) && (j != p);
+          if (ok && e1 > e0) {
+            const int tj = tag[j];
+            for (int e = e0; e < e1; ++e) if (excl_list[e] == tj) { ok = false; break; }
+          }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (ok) {
+          const int pos = cnt + __popcll(m & lanemask_lt());
+          if (pos < S) row[pos] = j;
+        }
+        cnt += __popcll(m);
+      }
+      finish_row(row, nn, p, cnt, S, l, ctl);
     }
   }
 }
@@ -379,7 +420,7 @@ __global__ __launch_bounds__(256) void k_nlist_brute(int n, const Vec4<R>* __res
     if (ok) { const int pos = cnt + __popcll(m & lanemask_lt()); if (pos < S) row[pos] = j; }
     cnt += __popcll(m);
   }
-  if (l == 0) { nn[p] = cnt < S ? cnt : S; if (cnt > S) atomicMax(&ctl->nl_overflow, cnt); }
+  finish_row(row, nn, p, cnt, S, l, ctl);
 }
 
 // =======================================================================================
@@ -394,7 +435,7 @@ __device__ __forceinline__ void pair_term(const PairCore<R> pc, const PairExt<R>
                                           R& fx, R& fy, R& fz, double& e_lj, double& e_tab, double& vir) {
   if (r2 <= pc.rc2) {
     if (pc.kind == (R)1) {
-      const R r2i = (R)1 / r2, r6i = r2i * r2i * r2i;
+      const R r2i = rcp_r(r2), r6i = r2i * r2i * r2i;
       const R ff = r6i * (pc.lj1 * r6i - pc.lj2) * r2i;
       fx += ff * dx; fy += ff * dy; fz += ff * dz;
       if (ENERGY) { const PairExt<R> px = pext[pidx]; e_lj += (double)(r6i * (px.e1 * r6i - px.e2) + px.shift); vir += (double)(ff * r2); }
@@ -434,17 +475,25 @@ __global__ __launch_bounds__(256) void k_pair_force(int n, const Vec4<R>* __rest
     const Vec4<R> xi = x4[i];
     const int ti = (int)xi.w;
     const int cnt = nn[i];
-    const int* row = nlist + (size_t)i * S;
+    const int4* row = reinterpret_cast<const int4*>(nlist + (size_t)i * S);
     const int pbase = ti * ntypes;
-    for (int k = sub; k < cnt; k += TPP) {
-      const int j = row[k];
-      const Vec4<R> xj = x4[j];
-      const R dx = minimg1<R>(xi.x - xj.x, box.L[0], box.invL[0]);
-      const R dy = minimg1<R>(xi.y - xj.y, box.L[1], box.invL[1]);
-      const R dz = minimg1<R>(xi.z - xj.z, box.L[2], box.invL[2]);
-      const R r2 = dx * dx + dy * dy + dz * dz;
-      const int pidx = pbase + (int)xj.w;
-      pair_term<R, ENERGY>(spc[pidx], pext, pidx, tab, r2, dx, dy, dz, fx, fy, fz, e_lj, e_tab, vir);
+    // lane `sub` takes 4 consecutive neighbours per trip: one 16-byte index load, then four
+    // independent position gathers in flight (rows are padded with the self index)
+    for (int k = sub * 4; k < cnt; k += TPP * 4) {
+      const int4 jj = row[k >> 2];
+      const Vec4<R> xa = x4[jj.x], xb = x4[jj.y], xc = x4[jj.z], xd = x4[jj.w];
+      const Vec4<R> xs[4] = {xa, xb, xc, xd};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const Vec4<R> xj = xs[u];
+        const R dx = minimg1<R>(xi.x - xj.x, box.L[0], box.invL[0]);
+        const R dy = minimg1<R>(xi.y - xj.y, box.L[1], box.invL[1]);
+        const R dz = minimg1<R>(xi.z - xj.z, box.L[2], box.invL[2]);
+        R r2 = dx * dx + dy * dy + dz * dz;
+        r2 = (k + u < cnt) ? r2 : (R)1e30;     // padding entries (self index) never interact
+        const int pidx = pbase + (int)xj.w;
+        pair_term<R, ENERGY>(spc[pidx], pext, pidx, tab, r2, dx, dy, dz, fx, fy, fz, e_lj, e_tab, vir);
+      }
     }
   }
   if (TPP > 1) {
@@ -463,6 +512,258 @@ __global__ __launch_bounds__(256) void k_pair_force(int n, const Vec4<R>* __rest
     if (threadIdx.x == 0) {
       double a = 0, b = 0, c = 0;
       for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += red[0][k]; b += red[1][k]; c += red[2][k]; }
+      eout[3 * blockIdx.x + 0] = 0.5 * a; eout[3 * blockIdx.x + 1] = 0.5 * b; eout[3 * blockIdx.x + 2] = 0.5 * c;
+    }
+  }
+}
+
+// =======================================================================================
+// Tiled path (production for boxes with >= HX+2, HY+2, HZ+2 cells per axis).
+//
+// A tile = a block of HX x HY x HZ home cells.  Its stencil, (HX+2) x (HY+2) x (HZ+2) cells,
+// is staged ONCE per workgroup into LDS with the periodic shift applied (coalesced 16-byte
+// loads, each cache line fetched once), instead of 74 divergent 16-byte gathers per particle
+// that cost one L1 line lookup each.  The neighbour list stores 16-bit slots of that LDS
+// image (tile-local indices): half the HBM bytes of an int32 list, no minimum-image
+// arithmetic in the pair loop, and the position gathers become ds_read_b128.
+// The staged order is a pure function of cell_start, which only changes at a rebuild, so the
+// build kernel and every later force launch see the same slot numbering.
+// =======================================================================================
+constexpr int HX = 4, HY = 2, HZ = 2;
+constexpr int SX = HX + 2, SY = HY + 2, SZ = HZ + 2;
+constexpr int NROW = SY * SZ;          // x-rows of the stencil
+constexpr int NHSEG = HY * HZ;         // home x-runs (contiguous in memory)
+
+// positions live in dynamic LDS (capacity chosen at run time from the cell occupancy):
+// sx[0..cap], slot `total` is a far-away dummy used as row padding
+template <typename R> struct TileLDS {
+  Vec4<R>* sx;
+  int rowoff[NROW + 1];                // first slot of each stencil row
+  int celloff[NROW][SX + 1];           // slot offset of every cell inside its row
+  int cellg[NROW][SX];                 // global index of the first particle of the cell
+  R cellshx[NROW][SX];                 // periodic shift in x (per cell), y/z (per row)
+  R rowshy[NROW], rowshz[NROW];
+  int hstart[NHSEG], hoff[NHSEG + 1];  // home x-runs: global start, prefix of counts
+  int geom[8];                         // hx, hy, hz, total, nhome
+};
+
+// fills the descriptor tables and stages the stencil.  wmode 0: .w = particle type (force
+// kernel), 1: .w = bits of the global index (list build).
+template <typename R>
+__device__ __forceinline__ Vec4<R>* dyn_lds() {
+  extern __shared__ __attribute__((aligned(16))) unsigned char chem_dyn_lds[];
+  return reinterpret_cast<Vec4<R>*>(((size_t)chem_dyn_lds + 15) & ~(size_t)15);
+}
+
+template <typename R>
+__device__ __forceinline__ void tile_stage(TileLDS<R>& T, const int CAP, int tile, const Vec4<R>* __restrict__ x4,
+                                           const int* __restrict__ cell_start, const Box<R>& box, int wmode, DevCtl* ctl) {
+  const int nx = box.nc[0], ny = box.nc[1], nz = box.nc[2];
+  const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
+  const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+  const int cx0 = tx * HX, cy0 = ty * HY, cz0 = tz * HZ;
+  const int hx = min(HX, nx - cx0), hy = min(HY, ny - cy0), hz = min(HZ, nz - cz0);
+  const int t = threadIdx.x;
+  if (t < NROW * SX) {
+    const int r = t / SX, k = t % SX, ry = r % SY, rz = r / SY;
+    int cnt = 0, g = 0; R shx = 0;
+    if (ry < hy + 2 && rz < hz + 2 && k < hx + 2) {
+      int ox = cx0 - 1 + k, oy = cy0 - 1 + ry, oz = cz0 - 1 + rz;
+      R shy = 0, shz = 0;
+      if (ox < 0) { ox += nx; shx = -box.L[0]; } else if (ox >= nx) { ox -= nx; shx = box.L[0]; }
+      if (oy < 0) { oy += ny; shy = -box.L[1]; } else if (oy >= ny) { oy -= ny; shy = box.L[1]; }
+      if (oz < 0) { oz += nz; shz = -box.L[2]; } else if (oz >= nz) { oz -= nz; shz = box.L[2]; }
+      const int oc = (oz * ny + oy) * nx + ox;
+      g = cell_start[oc]; cnt = cell_start[oc + 1] - g;
+      if (k == 0) { T.rowshy[r] = shy; T.rowshz[r] = shz; }
+    } else if (k == 0) { T.rowshy[r] = 0; T.rowshz[r] = 0; }
+    T.cellg[r][k] = g; T.cellshx[r][k] = shx;
+    T.celloff[r][k + 1] = cnt;   // turned into a prefix below
+  }
+  __syncthreads();
+  if (t < NROW) {
+    int o = 0; T.celloff[t][0] = 0;
+    for (int k = 0; k < SX; ++k) { o += T.celloff[t][k + 1]; T.celloff[t][k + 1] = o; }
+  }
+  __syncthreads();
+  if (t == 0) {
+    int o = 0;
+    for (int r = 0; r < NROW; ++r) { T.rowoff[r] = o; o += T.celloff[r][SX]; }
+    T.rowoff[NROW] = o;
+    if (o > CAP) atomicMax(&ctl->stage_overflow, o);
+    const int total = o < CAP ? o : CAP;
+    // home x-runs
+    int ho = 0;
+    for (int hzi = 0; hzi < HZ; ++hzi) for (int hyi = 0; hyi < HY; ++hyi) {
+      const int sgi = hzi * HY + hyi;
+      int st = 0, cn = 0;
+      if (hyi < hy && hzi < hz) {
+        const int c0 = ((cz0 + hzi) * ny + (cy0 + hyi)) * nx + cx0;
+        st = cell_start[c0]; cn = cell_start[c0 + hx] - st;
+      }
+      T.hstart[sgi] = st; T.hoff[sgi] = ho; ho += cn;
+    }
+    T.hoff[NHSEG] = ho;
+    T.geom[0] = hx; T.geom[1] = hy; T.geom[2] = hz; T.geom[3] = total; T.geom[4] = ho;
+    T.sx[total] = mk4<R>((R)1e18, (R)1e18, (R)1e18, (R)0);
+  }
+  __syncthreads();
+  const int w = t >> 6, l = t & 63, nw = blockDim.x >> 6;
+  for (int r = w; r < NROW; r += nw) {
+    const int len = T.celloff[r][SX], o0 = T.rowoff[r];
+    const R shy = T.rowshy[r], shz = T.rowshz[r];
+    for (int e = l; e < len; e += 64) {
+      int k = 0;
+#pragma unroll
+      for (int q = 1; q < SX; ++q) k += (e >= T.celloff[r][q]) ? 1 : 0;
+      const int g = T.cellg[r][k] + (e - T.celloff[r][k]);
+      const int dst = o0 + e;
+      if (dst < CAP) {
+        Vec4<R> p = x4[g];
+        p.x += T.cellshx[r][k]; p.y += shy; p.z += shz;
+        if (wmode) p.w = idx_as_real(g, (R)0);
+        T.sx[dst] = p;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ int ntiles_of(const int nc[3]) {
+  return ((nc[0] + HX - 1) / HX) * ((nc[1] + HY - 1) / HY) * ((nc[2] + HZ - 1) / HZ);
+}
+
+// ---- list build on tiles: 16-bit slot list (+ optional int32 global list for the reaction
+//      scan / diagnostics).  One wave per home particle, 64 staged candidates per instruction,
+//      __ballot + popcount compaction, coalesced row stores.
+template <typename R>
+__global__ __launch_bounds__(256) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+                                                     const int* __restrict__ cell_start, Box<R> box, R rl2,
+                                                     const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
+                                                     unsigned short* __restrict__ nl16, int S16, int* __restrict__ nlist, int S,
+                                                     int* __restrict__ nn, DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  __shared__ TileLDS<R> T;
+  if (threadIdx.x == 0) T.sx = dyn_lds<R>();
+  const int w = threadIdx.x >> 6, l = lane_id();
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    tile_stage<R>(T, CAP, tile, x4, cell_start, box, 1, ctl);
+    const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4];
+    for (int q = w; q < nhome; q += 4) {
+      int sgi = 0;
+#pragma unroll
+      for (int k = 1; k < NHSEG; ++k) sgi += (q >= T.hoff[k]) ? 1 : 0;
+      const int p = T.hstart[sgi] + (q - T.hoff[sgi]);
+      const int ly = sgi % HY, lz = sgi / HY;
+      // home cell along x: the home run is slots [celloff[hr][1], celloff[hr][hx+1]) of its own row
+      const int hr = (lz + 1) * SY + (ly + 1);
+      const int eh = (q - T.hoff[sgi]) + T.celloff[hr][1];
+      int lx = 0;
+      for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
+      const Vec4<R> xi = x4[p];
+      int e0 = 0, e1 = 0;
+      if (has_excl) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
+      int cnt = 0;
+      unsigned short* row16 = nl16 + (size_t)p * S16;
+      int* row32 = nlist ? nlist + (size_t)p * S : nullptr;
+      for (int dz = 0; dz < 3; ++dz) for (int dy = 0; dy < 3; ++dy) {
+        const int r = (lz + dz) * SY + (ly + dy);
+        const int a = T.rowoff[r] + T.celloff[r][lx], b = T.rowoff[r] + T.celloff[r][lx + 3];
+        for (int s0 = a; s0 < b; s0 += 64) {
+          const int s = s0 + l;
+          bool ok = s < b && s < total;
+          int j = -1;
+          if (ok) {
+            const Vec4<R> xj = T.sx[s];
+            j = real_as_idx(xj.w);
+            const R dx = xi.x - xj.x, dy_ = xi.y - xj.y, dz_ = xi.z - xj.z;
+            const R r2 = dx * dx + dy_ * dy_ + dz_ * dz_;
+            ok = (r2 <= rl2) && (j != p);
+            if (ok && e1 > e0) {
+              const int tj = tag[j];
+              for (int e = e0; e < e1; ++e) if (excl_list[e] == tj) { ok = false; break; }
+            }
+          }
+          const unsigned long long m = __ballot(ok);
+          if (ok) {
+            const int pos = cnt + __popcll(m & lanemask_lt());
+            if (pos < S16) { row16[pos] = (unsigned short)s; if (row32) row32[pos] = j; }
+          }
+          cnt += __popcll(m);
+        }
+      }
+      // pad to a multiple of 8 slots with the far-away dummy slot (row reads are 16-byte)
+      const int c = cnt < S16 ? cnt : S16;
+      const int pad = (8 - (c & 7)) & 7;
+      if (l < pad) { row16[c + l] = (unsigned short)total; }
+      if (row32 && l < ((4 - (c & 3)) & 3)) row32[c + l] = p;
+      if (l == 0) { nn[p] = c; if (cnt > S16) atomicMax(&ctl->nl_overflow, cnt); }
+    }
+  }
+}
+
+// ---- pair forces on tiles --------------------------------------------------------------
+template <typename R, int TPP, bool ENERGY>
+__global__ __launch_bounds__(256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
+                                                    const int* __restrict__ cell_start, const unsigned short* __restrict__ nl16,
+                                                    const int* __restrict__ nn, int S16, Box<R> box,
+                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
+                                                    int ntypes, const Vec4<R>* __restrict__ tab, double* __restrict__ eout,
+                                                    double half_skin, DevCtl* ctl) {
+  __shared__ TileLDS<R> T;
+  __shared__ PairCore<R> spc[kMaxTypes * kMaxTypes];
+  if (threadIdx.x == 0) T.sx = dyn_lds<R>();
+  for (int k = threadIdx.x; k < ntypes * ntypes; k += blockDim.x) spc[k] = pcore[k];
+  if (blockIdx.x == 0 && threadIdx.x == 0 && ctl->acc_maxdist > half_skin) ctl->skin_violation = 1;
+  const int tile = blockIdx.x;
+  __syncthreads();
+  tile_stage<R>(T, CAP, tile, x4, cell_start, box, 0, ctl);
+  const int nhome = T.geom[4];
+  const int slice = threadIdx.x / TPP, sub = threadIdx.x % TPP;
+  constexpr int NSL = 256 / TPP;
+  double e_lj = 0, e_tab = 0, vir = 0;
+  for (int q0 = 0; q0 < nhome; q0 += NSL) {
+    const int q = q0 + slice;
+    R fx = 0, fy = 0, fz = 0;
+    int p = -1;
+    if (q < nhome) {
+      int sgi = 0;
+#pragma unroll
+      for (int k = 1; k < NHSEG; ++k) sgi += (q >= T.hoff[k]) ? 1 : 0;
+      p = T.hstart[sgi] + (q - T.hoff[sgi]);
+      const Vec4<R> xi = x4[p];
+      const int pbase = (int)xi.w * ntypes;
+      const int cnt = nn[p];
+      const uint4* row = reinterpret_cast<const uint4*>(nl16 + (size_t)p * S16);
+      for (int k = sub * 8; k < cnt; k += TPP * 8) {
+        const uint4 pk = row[k >> 3];
+        const unsigned int wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s = (wds[u >> 1] >> ((u & 1) * 16)) & 0xffff;
+          const Vec4<R> xj = T.sx[s];
+          const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+          const R r2 = dx * dx + dy * dy + dz * dz;
+          const int pidx = pbase + (int)xj.w;
+          pair_term<R, ENERGY>(spc[pidx], pext, pidx, tab, r2, dx, dy, dz, fx, fy, fz, e_lj, e_tab, vir);
+        }
+      }
+    }
+    if (TPP > 1) {
+#pragma unroll
+      for (int o = TPP / 2; o > 0; o >>= 1) { fx += __shfl_xor(fx, o); fy += __shfl_xor(fy, o); fz += __shfl_xor(fz, o); }
+    }
+    if (p >= 0 && sub == 0) f4[p] = mk4<R>(fx, fy, fz, (R)0);
+  }
+  if (ENERGY) {
+    __shared__ double red[3][4];
+    for (int o = 32; o > 0; o >>= 1) { e_lj += __shfl_xor(e_lj, o); e_tab += __shfl_xor(e_tab, o); vir += __shfl_xor(vir, o); }
+    if (lane_id() == 0) { red[0][threadIdx.x >> 6] = e_lj; red[1][threadIdx.x >> 6] = e_tab; red[2][threadIdx.x >> 6] = vir; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0, b = 0, c = 0;
+      for (int k = 0; k < 4; ++k) { a += red[0][k]; b += red[1][k]; c += red[2][k]; }
       eout[3 * blockIdx.x + 0] = 0.5 * a; eout[3 * blockIdx.x + 1] = 0.5 * b; eout[3 * blockIdx.x + 2] = 0.5 * c;
     }
   }
@@ -619,8 +920,12 @@ __global__ __launch_bounds__(256) void k_react_scan(int n, const Vec4<R>* __rest
     for (int k = threadIdx.x; k < (int)(sizeof(ReactSet) / 4); k += blockDim.x) dst[k] = src[k];
   }
   __syncthreads();
-  // 8 lanes per particle row
+  // 8 lanes per particle row; hits are staged per wave in LDS (wave-private region)
   constexpr int TPP = 8;
+  constexpr int kWaveBuf = 192;
+  __shared__ Candidate sbuf[4 * kWaveBuf];
+  Candidate* wbuf = sbuf + (threadIdx.x >> 6) * kWaveBuf;
+  int wcount = 0;   // wave-uniform
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = gid / TPP, sub = gid % TPP;
   int cnt = 0, ti = 0, si = 0, tgi = 0, ri = 0, mi = 0;
@@ -679,17 +984,25 @@ __global__ __launch_bounds__(256) void k_react_scan(int n, const Vec4<R>* __rest
         }
         const unsigned long long m = __ballot(hit);
         if (m) {
-          int base = 0;
-          if (lane_id() == 0) base = atomicAdd(&ctl->cand_count, __popcll(m));
-          base = __shfl(base, 0);
-          if (hit) {
-            const int pos = base + __popcll(m & lanemask_lt());
-            if (pos < cand_cap) cand[pos] = Candidate{a, b, q, h, d2};
-            else ctl->cand_overflow = 1;
+          const int nh = __popcll(m);
+          if (wcount + nh > kWaveBuf) {   // flush this wave's staged hits: one global atomic per flush
+            int base = 0;
+            if (lane_id() == 0) base = atomicAdd(&ctl->cand_count, wcount);
+            base = __shfl(base, 0);
+            for (int t = lane_id(); t < wcount; t += 64) { if (base + t < cand_cap) cand[base + t] = wbuf[t]; else ctl->cand_overflow = 1; }
+            wcount = 0;
           }
+          if (hit) wbuf[wcount + __popcll(m & lanemask_lt())] = Candidate{a, b, q, h, d2};
+          wcount += nh;
         }
       }
     }
+  }
+  if (wcount > 0) {
+    int base = 0;
+    if (lane_id() == 0) base = atomicAdd(&ctl->cand_count, wcount);
+    base = __shfl(base, 0);
+    for (int t = lane_id(); t < wcount; t += 64) { if (base + t < cand_cap) cand[base + t] = wbuf[t]; else ctl->cand_overflow = 1; }
   }
 }
 
@@ -749,7 +1062,7 @@ __global__ void k_res_round(int nc, const Candidate* __restrict__ c, const int* 
       if (so == 2) dead = true;
       else if (so == 1 && cand_less(c[o], c[k], nearest)) ismin = false;
     }
-    if (dead) s = 0; else if (ismin) { s = 2; atomicAdd(&ctl->accepted, 1); } else atomicAdd(&ctl->alive, 1);
+    if (dead) s = 0; else if (ismin) s = 2; else ctl->alive = 1;
   }
   st_out[k] = s;
 }

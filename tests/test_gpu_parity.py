@@ -49,6 +49,30 @@ def test_pair_kernel_lane_widths_agree(make_gpu, make_oracle, tpp):
     assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-10
 
 
+@pytest.mark.parametrize("prec", [64, 32])
+def test_tiled_and_per_cell_paths_agree(make_gpu, make_oracle, prec):
+    """LDS-tiled list/force kernels (ragged 7x7x7 cell grid) vs the per-cell fall-back vs the oracle."""
+    spec = W.reactive_melt(n=8788, seed=5)
+    spec["exclusions"] = np.stack([np.arange(1, 2001, 2), np.arange(2, 2002, 2)], 1)
+    a, b, o = make_gpu(prec), make_gpu(prec), make_oracle()
+    for e in (a, b, o):
+        W.apply(spec, e, thermostat=False, reactions=False)
+    b.set_option("tiles", 0)
+    for e in (a, b, o):
+        e.run(0)
+    fo = o.get_state("FORCE")
+    assert rel_err(a.get_state("FORCE"), fo) < TOL[prec]
+    assert rel_err(b.get_state("FORCE"), fo) < TOL[prec]
+    assert np.array_equal(a.get_verlet_pairs(), b.get_verlet_pairs())
+    if prec == 64:
+        assert np.array_equal(a.get_verlet_pairs(), o.get_verlet_pairs())
+    oa, oo = a.observe(), o.observe()
+    assert oa["epot_lj"] == pytest.approx(oo["epot_lj"], rel=1e-11 if prec == 64 else 2e-6)
+    a.run(30); b.run(30); o.run(30)
+    assert rel_err(a.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 1e-4)
+    assert rel_err(b.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 1e-4)
+
+
 def test_small_box_brute_force_list(make_gpu, make_oracle):
     # box edge < 3 (rc+skin): the list is built by the brute-force kernel with minimum image
     rng = np.random.default_rng(3)
