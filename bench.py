@@ -34,6 +34,7 @@ def parse():
     p.add_argument("--precision", type=int, default=32)
     p.add_argument("--cpu-steps", type=int, default=8, help="oracle steps for the cpu_baseline leg (0 = skip)")
     p.add_argument("--tpp", type=int, default=0)
+    p.add_argument("--opt", action="append", default=[], help="name=value engine option (tuning)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--verbose", action="store_true", help="timers to stderr")
     return p.parse_args()
@@ -79,6 +80,9 @@ def main():
     W.apply(spec, eng)
     if a.tpp:
         eng.set_option("tpp", a.tpp)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, float(v))
     eng.run(a.warmup)
     eng.sync()
     ev0 = len(eng.get_events())

@@ -74,6 +74,8 @@ struct Ctx {
   int opt_time_pair = 0;    // HIP-event timing of every pair-force launch
   int opt_fuse = 1;         // fused integrate2+integrate1
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
+  int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
+  int opt_skip_inactive = 1; // force list omits type pairs without a potential
   chem_timers tm{};
   virtual ~Ctx() {}
   virtual void run(int64_t nsteps) = 0;
@@ -83,10 +85,15 @@ struct Ctx {
   virtual void modify_particle(int tag, int what, double value) = 0;
   virtual void sync() = 0;
   virtual void refresh_timers() {}
+  virtual void set_pair_bs(int) {}
+  virtual int64_t debug_dump(long long*, int64_t) { return 0; }
+  virtual void debug_enable(int) {}
 };
 
 template <typename R> struct CtxT : Ctx {
   using V4 = Vec4<R>;
+  int pair_bs = 512;
+  bool lj_only = true;
   int tile_cap = 0;       // LDS slots of one staged tile (dynamic LDS)
   size_t tile_lds_bytes() const { return (size_t)(tile_cap + 2) * sizeof(V4) + 16; }
   hipStream_t stream = nullptr;
@@ -95,10 +102,13 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> tag, tago, rtag, state, res_id, mol_id;
   DBuf<int4> img4, img4o;
   DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
-  DBuf<int> nlist, nn;
+  DBuf<int> nlist, nn, nnh;
   DBuf<unsigned short> nl16;
+  DBuf<TileLDS<R>> tdesc;
+  DBuf<long long> dbgbuf; bool dbg_on = false;
   int S = 0;
-  bool use_tiles = false, want32 = true;
+  bool use_tiles = false, want32 = false;   // int32 list only built on demand (reaction steps, diagnostics)
+  ActMask act{}; UniLJ uni{}; bool uniform_lj = false;
   int ntiles = 0;
   DBuf<int> excl_start, excl_list; int has_excl = 0;
   DBuf<int> bstart; DBuf<BondedEntry> bent; DBuf<BondedParam> bpar; int64_t nbent = 0;
@@ -166,18 +176,20 @@ template <typename R> struct CtxT : Ctx {
   void set_tile_lds_attr() {
     const int bytes = (int)tile_lds_bytes();
 #define SETA(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
-    SETA(k_nlist_tiles<R>);
-    SETA((k_pair_tiles<R, 1, false>)); SETA((k_pair_tiles<R, 2, false>)); SETA((k_pair_tiles<R, 4, false>));
-    SETA((k_pair_tiles<R, 8, false>)); SETA((k_pair_tiles<R, 16, false>));
-    SETA((k_pair_tiles<R, 1, true>)); SETA((k_pair_tiles<R, 2, true>)); SETA((k_pair_tiles<R, 4, true>));
-    SETA((k_pair_tiles<R, 8, true>)); SETA((k_pair_tiles<R, 16, true>));
+    SETA((k_nlist_tiles<R, 512>));
+#define SETB(T, E, M) SETA((k_pair_tiles<R, T, E, 256, M>)); SETA((k_pair_tiles<R, T, E, 512, M>)); SETA((k_pair_tiles<R, T, E, 1024, M>))
+#define SETT(E, M) SETB(1, E, M); SETB(2, E, M); SETB(4, E, M); SETB(8, E, M)
+    SETT(false, 2); SETT(false, 1); SETT(false, 0); SETT(true, 0);
+#undef SETT
+#undef SETB
 #undef SETA
   }
 
   void alloc_lists() {
     nlist.free(); nl16.free();
-    if (!use_tiles || want32) nlist.alloc((size_t)n * S);
-    if (use_tiles) nl16.alloc((size_t)n * S);
+    nlist.alloc((size_t)n * S);
+    nnh.alloc(n);
+    if (use_tiles) { nl16.alloc((size_t)n * S); HIPCHK(hipMemsetAsync(nl16.p, 0, (size_t)n * S * 2, stream)); tdesc.alloc(ntiles); }
     tm.nlist_capacity = S;
   }
 
@@ -243,6 +255,26 @@ template <typename R> struct CtxT : Ctx {
       }
       hc[(size_t)a * nt + b] = c; he[(size_t)a * nt + b] = e;
     }
+    lj_only = htab.empty();
+    // type pairs with a potential; uniform LJ = every active pair shares one parameter set
+    std::memset(&act, 0, sizeof(act));
+    uniform_lj = lj_only;
+    const HostPairPot* first = nullptr;
+    for (int a = 0; a < CHEM_MAX_TYPES; ++a) for (int b = 0; b < CHEM_MAX_TYPES; ++b) {
+      const HostPairPot& p = pp[a][b];
+      if (!opt_skip_inactive || p.kind) act.row[a] |= 1u << b;
+      if (p.kind == 1) {
+        if (!first) first = &p;
+        else if (p.eps != first->eps || p.sig != first->sig || p.rc != first->rc) uniform_lj = false;
+      }
+    }
+    if (!opt_skip_inactive || !first) uniform_lj = false;
+    if (uniform_lj) {
+      const double s6 = std::pow(first->sig, 6), s12 = s6 * s6;
+      uni.drc2 = first->rc * first->rc; uni.dlj1 = 48.0 * first->eps * s12; uni.dlj2 = 24.0 * first->eps * s6;
+      uni.rc2 = (float)uni.drc2; uni.lj1 = (float)uni.dlj1; uni.lj2 = (float)uni.dlj2;
+    }
+    resort = true;   // the force list depends on the type-pair mask
     pcore.upload(hc, stream); pext.upload(he, stream); tab.upload(htab, stream);
     HIPCHK(hipStreamSynchronize(stream));
     pair_dirty = false;
@@ -293,10 +325,12 @@ template <typename R> struct CtxT : Ctx {
                        x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
     hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, n, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, c);
     const R rl2 = (R)((rc + skin) * (rc + skin));
-    if (use_tiles)
-      hipLaunchKernelGGL((k_nlist_tiles<R>), dim3(std::min(ntiles, 1280)), dim3(256), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, cell_start.p, box, rl2,
-                         excl_start.p, excl_list.p, has_excl, nl16.p, S, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
-    else if (box.nc[0] > 0)
+    if (use_tiles) {
+      hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c);
+      hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
+      hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(std::min((ntiles + 7) / 8 * 8, 1024)), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
+                         excl_start.p, excl_list.p, has_excl, act, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
+    } else if (box.nc[0] > 0)
       hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
                          excl_start.p, excl_list.p, has_excl, nlist.p, nn.p, S, c);
     else
@@ -342,17 +376,22 @@ template <typename R> struct CtxT : Ctx {
 
   // ---- forces -------------------------------------------------------------------------
   int pick_tpp() const {
-    if (opt_tpp > 0) return use_tiles ? std::min(opt_tpp, 16) : opt_tpp;
-    if (use_tiles) return 4;
+    if (opt_tpp > 0) return use_tiles ? std::min(opt_tpp, 8) : opt_tpp;
+    if (use_tiles) return 2;
     return n >= 100000 ? 4 : (n >= 8000 ? 8 : 16);
   }
 
   template <bool ENERGY> int launch_pair(V4* fdst, int tpp) {
     const double hs = 0.5 * skin;
     if (use_tiles) {
-#define LT(T) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY>), dim3(ntiles), dim3(256), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, fdst, cell_start.p, \
-                                 nl16.p, nn.p, S, box, pcore.p, pext.p, ntypes, tab.p, eout.p, hs, ctl.p)
-      switch (tpp) { case 1: LT(1); break; case 2: LT(2); break; case 4: LT(4); break; case 8: LT(8); break; default: LT(16); break; }
+#define LT(T, M, B) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M>), dim3(ntiles), dim3(B), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, fdst, tdesc.p, \
+                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr)
+#define LTB(T, M) do { if (pair_bs == 256) LT(T, M, 256); else if (pair_bs == 512) LT(T, M, 512); else LT(T, M, 1024); } while (0)
+#define LTT(M) do { switch (tpp) { case 1: LTB(1, M); break; case 2: LTB(2, M); break; case 8: LTB(8, M); break; default: LTB(4, M); break; } } while (0)
+      const int mode = ENERGY ? 0 : (uniform_lj ? 2 : (lj_only ? 1 : 0));
+      if (mode == 2) LTT(2); else if (mode == 1) LTT(1); else LTT(0);
+#undef LTT
+#undef LTB
 #undef LT
       return ntiles;
     }
@@ -444,8 +483,13 @@ template <typename R> struct CtxT : Ctx {
     }
   }
 
+  // The int32 Verlet list (all pairs within rc+skin) is only needed by the reaction scan and by
+  // diagnostics: it is produced by a forced rebuild right there instead of at every rebuild.
   void ensure_list32() {
-    if (use_tiles && !want32) { want32 = true; nlist.alloc((size_t)n * S); resort = true; }
+    if (!use_tiles) { if (resort) rebuild_now(); return; }
+    want32 = true;
+    rebuild_now();
+    want32 = false;
   }
 
   // ---- reactions ----------------------------------------------------------------------
@@ -472,6 +516,7 @@ template <typename R> struct CtxT : Ctx {
     }
     HIPCHK(hipMemcpyAsync(rs_dev.p, &rs, sizeof(ReactSet), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    ensure_list32();
     set_ctl_field(&DevCtl::cand_count, 0);
     hipLaunchKernelGGL(k_react_scan<R>, dim3(cdiv((long long)n * 8, 256)), dim3(256), 0, stream, n, x4.p, tag.p, nlist.p, nn.p, S, state.p,
                        res_id.p, mol_id.p, boxd, rs_dev.p, cand.p, cand_cap, ctl.p);
@@ -533,7 +578,9 @@ template <typename R> struct CtxT : Ctx {
       upload_bonded(); upload_excl();
       resort = true;
       set_ctl_field(&DevCtl::force_rebuild, 1);
-    } else if (types_changed) {
+    }
+    if (types_changed) { resort = true; set_ctl_field(&DevCtl::force_rebuild, 1); }   // force list depends on types
+    if (newbonds.empty() && types_changed) {
       bool any_typed = false;
       for (auto& l : top.lists) any_typed |= l.by_types != 0;
       if (any_typed) upload_bonded();
@@ -611,7 +658,6 @@ template <typename R> struct CtxT : Ctx {
   int64_t verlet_pairs(int64_t* out, int64_t cap) override {
     flush_host_state();
     ensure_list32();
-    if (resort) rebuild_now();
     std::vector<int> hn, ht, hl;
     nn.download(hn, n, stream); tag.download(ht, n, stream); nlist.download(hl, (size_t)n * S, stream);
     std::vector<std::pair<int64_t, int64_t>> pr;
@@ -629,9 +675,19 @@ template <typename R> struct CtxT : Ctx {
     return m;
   }
 
+  void set_pair_bs(int v) override { pair_bs = v; }
+  void debug_enable(int on) override { dbg_on = on != 0; if (dbg_on) { dbgbuf.alloc(6 * (size_t)std::max(ntiles, 1)); } }
+  int64_t debug_dump(long long* out, int64_t cap) override {
+    if (!dbg_on) return 0;
+    std::vector<long long> h; dbgbuf.download(h, 6 * (size_t)ntiles, stream);
+    const int64_t m = std::min<int64_t>(cap, (int64_t)h.size());
+    std::copy(h.begin(), h.begin() + m, out);
+    return m;
+  }
+
   void refresh_timers() override {
     if (!device_ready || particles_dirty) return;
-    std::vector<int> hn; nn.download(hn, n, stream);
+    std::vector<int> hn; (use_tiles ? nnh : nn).download(hn, n, stream);
     long long tot = 0; for (int v : hn) tot += v;
     tm.nlist_entries = tot; tm.nlist_capacity = S;
   }
@@ -714,7 +770,7 @@ int chem_set_particles(chem_ctx* ctx, int64_t n, const int64_t* id, const int32_
                        const double* mass, const double* q, const int32_t* state, const int32_t* res_id) {
   API_BEGIN
   REQUIRE(n > 0 && id && type && pos && mass, CHEM_EINVAL, "set_particles: null or empty input");
-  REQUIRE(n < (1ll << 28), CHEM_EINVAL, "set_particles: too many particles for one context");
+  REQUIRE(n < (1ll << 27), CHEM_EINVAL, "set_particles: too many particles for one context");
   Ctx& c = CTX; HostTopology& t = c.top;
   std::vector<int64_t> order(n);
   for (int64_t i = 0; i < n; ++i) order[i] = i;
@@ -747,7 +803,7 @@ int chem_modify_particle(chem_ctx* ctx, int64_t id, int what, double value) {
   API_BEGIN
   Ctx& c = CTX; const int t = c.top.tag_of(id);
   REQUIRE(t >= 0, CHEM_EINVAL, "modify_particle: unknown id");
-  if (what == CHEM_STATE_TYPE) { REQUIRE(value >= 0 && value < CHEM_MAX_TYPES, CHEM_EINVAL, "type"); c.top.type[t] = (int)value; c.pair_dirty = true; c.bonded_dirty = true; }
+  if (what == CHEM_STATE_TYPE) { REQUIRE(value >= 0 && value < CHEM_MAX_TYPES, CHEM_EINVAL, "type"); c.top.type[t] = (int)value; c.pair_dirty = true; c.bonded_dirty = true; c.resort = true; }
   else if (what == CHEM_STATE_STATE) c.top.state[t] = (int)value;
   else if (what == CHEM_STATE_MASS) { REQUIRE(value > 0, CHEM_EINVAL, "mass"); c.top.mass[t] = value; }
   else if (what == CHEM_STATE_RESID) c.top.res_id[t] = (int)value;
@@ -982,10 +1038,17 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "time_pair_kernel") CTX.opt_time_pair = value != 0;
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
+  else if (k == "pair_block") { const int v = (int)value; REQUIRE(v == 256 || v == 512 || v == 1024, CHEM_EINVAL, "pair_block must be 256, 512 or 1024"); CTX.set_pair_bs(v); }
+  else if (k == "ablate") CTX.opt_ablate = (int)value;
+  else if (k == "debug_stamps") CTX.debug_enable((int)value);
+  else if (k == "skip_inactive_pairs") { CTX.opt_skip_inactive = value != 0; CTX.pair_dirty = true; }
   else throw ChemError(CHEM_EINVAL, "unknown option " + k);
   return 0;
   API_END(ctx)
 }
+
+// diagnostic: per-tile phase stamps of the last pair-force launch (6 int64 per tile); not part of the public header
+int64_t chem_debug_dump(chem_ctx* ctx, long long* out, int64_t cap) { return ctx->c->debug_dump(out, cap); }
 
 int chem_comm_unique_id(char uid[128]) { (void)uid; return CHEM_ENOTIMPL; }
 int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], const char uid[128]) {

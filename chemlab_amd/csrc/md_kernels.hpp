@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void k_pair_force(int n, const Vec4<R>* __rest
 // The staged order is a pure function of cell_start, which only changes at a rebuild, so the
 // build kernel and every later force launch see the same slot numbering.
 // =======================================================================================
-constexpr int HX = 4, HY = 2, HZ = 2;
+constexpr int HX = 3, HY = 3, HZ = 3;   // ~490 home particles at 18/cell: one pass of a 512-thread block; stencil 5^3 cells (x4.6)
 constexpr int SX = HX + 2, SY = HY + 2, SZ = HZ + 2;
 constexpr int NROW = SY * SZ;          // x-rows of the stencil
 constexpr int NHSEG = HY * HZ;         // home x-runs (contiguous in memory)
@@ -537,7 +537,6 @@ constexpr int NHSEG = HY * HZ;         // home x-runs (contiguous in memory)
 // positions live in dynamic LDS (capacity chosen at run time from the cell occupancy):
 // sx[0..cap], slot `total` is a far-away dummy used as row padding
 template <typename R> struct TileLDS {
-  Vec4<R>* sx;
   int rowoff[NROW + 1];                // first slot of each stencil row
   int celloff[NROW][SX + 1];           // slot offset of every cell inside its row
   int cellg[NROW][SX];                 // global index of the first particle of the cell
@@ -547,17 +546,19 @@ template <typename R> struct TileLDS {
   int geom[8];                         // hx, hy, hz, total, nhome
 };
 
-// fills the descriptor tables and stages the stencil.  wmode 0: .w = particle type (force
-// kernel), 1: .w = bits of the global index (list build).
-template <typename R>
-__device__ __forceinline__ Vec4<R>* dyn_lds() {
-  extern __shared__ __attribute__((aligned(16))) unsigned char chem_dyn_lds[];
-  return reinterpret_cast<Vec4<R>*>(((size_t)chem_dyn_lds + 15) & ~(size_t)15);
-}
+// NOTE: the pointer must stay a plain local derived from the extern array (no integer
+// round-trip, never stored in memory) so that the compiler keeps it in the LDS address space
+// and emits ds_read/ds_write instead of flat_* accesses.
+#define CHEM_DYN_LDS(R) \
+  extern __shared__ __attribute__((aligned(16))) unsigned char chem_dyn_lds[]; \
+  Vec4<R>* const sx = reinterpret_cast<Vec4<R>*>(chem_dyn_lds)
 
+// Descriptor tables of one tile, computed ONCE per rebuild by k_tile_desc and kept in HBM
+// (~1.3 KB per tile); every later launch copies them into LDS with one coalesced read instead
+// of re-deriving them through dependent global loads and three barrier phases.
 template <typename R>
-__device__ __forceinline__ void tile_stage(TileLDS<R>& T, const int CAP, int tile, const Vec4<R>* __restrict__ x4,
-                                           const int* __restrict__ cell_start, const Box<R>& box, int wmode, DevCtl* ctl) {
+__device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int tile, const int* __restrict__ cell_start,
+                                            const Box<R>& box, DevCtl* ctl) {
   const int nx = box.nc[0], ny = box.nc[1], nz = box.nc[2];
   const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
   const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
@@ -592,7 +593,6 @@ __device__ __forceinline__ void tile_stage(TileLDS<R>& T, const int CAP, int til
     T.rowoff[NROW] = o;
     if (o > CAP) atomicMax(&ctl->stage_overflow, o);
     const int total = o < CAP ? o : CAP;
-    // home x-runs
     int ho = 0;
     for (int hzi = 0; hzi < HZ; ++hzi) for (int hyi = 0; hyi < HY; ++hyi) {
       const int sgi = hzi * HY + hyi;
@@ -605,14 +605,83 @@ __device__ __forceinline__ void tile_stage(TileLDS<R>& T, const int CAP, int til
     }
     T.hoff[NHSEG] = ho;
     T.geom[0] = hx; T.geom[1] = hy; T.geom[2] = hz; T.geom[3] = total; T.geom[4] = ho;
-    T.sx[total] = mk4<R>((R)1e18, (R)1e18, (R)1e18, (R)0);
   }
   __syncthreads();
-  const int w = t >> 6, l = t & 63, nw = blockDim.x >> 6;
-  for (int r = w; r < NROW; r += nw) {
+}
+
+template <typename R>
+__global__ __launch_bounds__(128) void k_tile_desc(int ntiles, int CAP, const int* __restrict__ cell_start, Box<R> box,
+                                                   TileLDS<R>* __restrict__ desc, DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  __shared__ TileLDS<R> T;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();
+    tile_tables<R>(T, CAP, tile, cell_start, box, ctl);
+    const int* src = reinterpret_cast<const int*>(&T);
+    int* dst = reinterpret_cast<int*>(&desc[tile]);
+    for (int k = threadIdx.x; k < (int)(sizeof(TileLDS<R>) / 4); k += blockDim.x) dst[k] = src[k];
+  }
+}
+
+template <typename R>
+__device__ __forceinline__ void tile_load_desc(TileLDS<R>& T, const TileLDS<R>* __restrict__ desc, int tile) {
+  const int* src = reinterpret_cast<const int*>(&desc[tile]);
+  int* dst = reinterpret_cast<int*>(&T);
+  for (int k = threadIdx.x; k < (int)(sizeof(TileLDS<R>) / 4); k += blockDim.x) dst[k] = src[k];
+}
+
+// stages the stencil of the tile described by T into sx.  wmode 0: .w = particle type (force
+// kernel), 1: .w = (global index << 4 | type) (list build).  Caller synchronises afterwards.
+// All global loads of a wave are issued before the first LDS write so that the staging costs one
+// memory latency, not one per row chunk.
+template <typename R, int BS>
+__device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx, const int CAP,
+                                          const Vec4<R>* __restrict__ x4, int wmode) {
+  constexpr int NW = BS / 64, RPW = (NROW + NW - 1) / NW;
+  const int t = threadIdx.x;
+  const int w = t >> 6, l = t & 63;
+  if (t == 0) sx[T.geom[3]] = mk4<R>((R)1e18, (R)1e18, (R)1e18, (R)0);
+  Vec4<R> pv[RPW][2];
+  int pk_[RPW][2], pg[RPW][2];
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int r = w + rr * NW;
+    const int len = r < NROW ? T.celloff[r][SX] : 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int e = l + 64 * c;
+      pk_[rr][c] = -1;
+      if (e < len) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < SX; ++q) k += (e >= T.celloff[r][q]) ? 1 : 0;
+        const int g = T.cellg[r][k] + (e - T.celloff[r][k]);
+        pk_[rr][c] = k; pg[rr][c] = g;
+        pv[rr][c] = x4[g];
+      }
+    }
+  }
+#pragma unroll
+  for (int rr = 0; rr < RPW; ++rr) {
+    const int r = w + rr * NW;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int k = pk_[rr][c];
+      if (k >= 0) {
+        const int dst = T.rowoff[r] + l + 64 * c;
+        if (dst < CAP) {
+          Vec4<R> p = pv[rr][c];
+          p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
+          if (wmode) p.w = idx_as_real((pg[rr][c] << 4) | (int)p.w, (R)0);
+          sx[dst] = p;
+        }
+      }
+    }
+  }
+  // rows longer than 128 particles (crowded cells): remainder, serial
+  for (int r = w; r < NROW; r += NW) {
     const int len = T.celloff[r][SX], o0 = T.rowoff[r];
-    const R shy = T.rowshy[r], shz = T.rowshz[r];
-    for (int e = l; e < len; e += 64) {
+    for (int e = l + 128; e < len; e += 64) {
       int k = 0;
 #pragma unroll
       for (int q = 1; q < SX; ++q) k += (e >= T.celloff[r][q]) ? 1 : 0;
@@ -620,135 +689,270 @@ __device__ __forceinline__ void tile_stage(TileLDS<R>& T, const int CAP, int til
       const int dst = o0 + e;
       if (dst < CAP) {
         Vec4<R> p = x4[g];
-        p.x += T.cellshx[r][k]; p.y += shy; p.z += shz;
-        if (wmode) p.w = idx_as_real(g, (R)0);
-        T.sx[dst] = p;
+        p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
+        if (wmode) p.w = idx_as_real((g << 4) | (int)p.w, (R)0);
+        sx[dst] = p;
       }
     }
   }
-  __syncthreads();
+}
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 nt_load_u4(const uint4* p) {
+  const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// XCD-aware work-item order (speed only, never correctness): workgroups are dealt round-robin
+// over the 8 XCDs, so block b and b+8 share an L2.  Remapping gives every XCD one contiguous
+// range of tiles (a z-slab of the box): its 4 MiB L2 then holds the slab's positions and the
+// stencil staging hits L2 instead of pulling the whole position array through the fabric.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
 __device__ __forceinline__ int ntiles_of(const int nc[3]) {
   return ((nc[0] + HX - 1) / HX) * ((nc[1] + HY - 1) / HY) * ((nc[2] + HZ - 1) / HZ);
 }
 
-// ---- list build on tiles: 16-bit slot list (+ optional int32 global list for the reaction
-//      scan / diagnostics).  One wave per home particle, 64 staged candidates per instruction,
-//      __ballot + popcount compaction, coalesced row stores.
-template <typename R>
-__global__ __launch_bounds__(256) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
-                                                     const int* __restrict__ cell_start, Box<R> box, R rl2,
-                                                     const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
-                                                     unsigned short* __restrict__ nl16, int S16, int* __restrict__ nlist, int S,
-                                                     int* __restrict__ nn, DevCtl* ctl) {
+// ---- list build on tiles.  Two products from one sweep:
+//   nl16/nnh  : 16-bit LDS slots of the pairs that carry a non-bonded potential (type-pair mask
+//               `act`; e.g. A-B and A-D of chain_growth_catalytic/topol.top:16-17 are off) -- read by
+//               the force kernel every step.  Layout is tile-major and transposed: the 8-slot chunk c
+//               of home particle q of a tile lives at  base + (c*nhome + q)*8,  so that consecutive
+//               lanes (= consecutive home particles) read consecutive 16-byte words.
+//   nlist/nn  : int32 global indices of ALL non-excluded pairs within rc+skin (the Verlet list the
+//               reaction scan and diagnostics traverse) -- only when `nlist` is non-null.
+// One lane per home particle walks the nine x-runs of its 27-cell stencil in the staged LDS image:
+// no cross-lane traffic, every lane does useful work (the wave-per-particle ballot version spent
+// ~7x more instructions per accepted pair).
+struct ActMask { unsigned int row[kMaxTypes]; };   // bit tj of row[ti]: pair (ti,tj) has a potential
+
+template <typename R, int BS>
+__global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+                                                    const TileLDS<R>* __restrict__ desc, R rl2,
+                                                    const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
+                                                    ActMask act, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
+                                                    int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
   __shared__ TileLDS<R> T;
-  if (threadIdx.x == 0) T.sx = dyn_lds<R>();
-  const int w = threadIdx.x >> 6, l = lane_id();
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  CHEM_DYN_LDS(R);
+  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    const int tile = xcd_remap(vb, ntiles);     // gridDim.x is a multiple of 8: vb % 8 == blockIdx.x % 8
     __syncthreads();
-    tile_stage<R>(T, CAP, tile, x4, cell_start, box, 1, ctl);
-    const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4];
-    for (int q = w; q < nhome; q += 4) {
+    tile_load_desc<R>(T, desc, tile);
+    __syncthreads();
+    tile_fill<R, BS>(T, sx, CAP, x4, 1);
+    __syncthreads();
+    const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4], hbase = T.geom[5];
+    unsigned short* reg16 = nl16 + (size_t)hbase * S16;
+    for (int q = threadIdx.x; q < nhome; q += BS) {
       int sgi = 0;
 #pragma unroll
       for (int k = 1; k < NHSEG; ++k) sgi += (q >= T.hoff[k]) ? 1 : 0;
-      const int p = T.hstart[sgi] + (q - T.hoff[sgi]);
+      const int inrun = q - T.hoff[sgi];
+      const int p = T.hstart[sgi] + inrun;
       const int ly = sgi % HY, lz = sgi / HY;
-      // home cell along x: the home run is slots [celloff[hr][1], celloff[hr][hx+1]) of its own row
       const int hr = (lz + 1) * SY + (ly + 1);
-      const int eh = (q - T.hoff[sgi]) + T.celloff[hr][1];
+      const int eh = inrun + T.celloff[hr][1];
       int lx = 0;
       for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
-      const Vec4<R> xi = x4[p];
+      const Vec4<R> xi = sx[T.rowoff[hr] + eh];
+      const unsigned int arow = act.row[real_as_idx(xi.w) & 15];
       int e0 = 0, e1 = 0;
       if (has_excl) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
-      int cnt = 0;
-      unsigned short* row16 = nl16 + (size_t)p * S16;
+      int cnt = 0, cnt16 = 0;
       int* row32 = nlist ? nlist + (size_t)p * S : nullptr;
+      uint4* regq = reinterpret_cast<uint4*>(reg16) + q;   // chunk c of this particle: regq[c * nhome]
+      // accepted slots are shifted into a 128-bit register; every 8th append stores one whole
+      // 16-byte chunk (instead of eight scattered 2-byte stores)
+      uint4 acc = make_uint4(0, 0, 0, 0);
+      auto push = [&](unsigned int sl) {
+        acc.x = __builtin_amdgcn_alignbit(acc.y, acc.x, 16);
+        acc.y = __builtin_amdgcn_alignbit(acc.z, acc.y, 16);
+        acc.z = __builtin_amdgcn_alignbit(acc.w, acc.z, 16);
+        acc.w = (acc.w >> 16) | (sl << 16);
+        if ((cnt16 & 7) == 7 && cnt16 < S16) regq[(size_t)(cnt16 >> 3) * nhome] = acc;
+        ++cnt16;
+      };
+      auto hit = [&](int s, int jw) {
+        const int j = jw >> 4;
+        bool ok = j != p;
+        if (ok && e1 > e0) {
+          const int tgj = tag[j];
+          for (int e = e0; e < e1; ++e) if (excl_list[e] == tgj) { ok = false; break; }
+        }
+        if (ok) {
+          if ((arow >> (jw & 15)) & 1u) push((unsigned int)s);
+          if (row32) { if (cnt < S) row32[cnt] = j; ++cnt; }
+        }
+      };
       for (int dz = 0; dz < 3; ++dz) for (int dy = 0; dy < 3; ++dy) {
         const int r = (lz + dz) * SY + (ly + dy);
-        const int a = T.rowoff[r] + T.celloff[r][lx], b = T.rowoff[r] + T.celloff[r][lx + 3];
-        for (int s0 = a; s0 < b; s0 += 64) {
-          const int s = s0 + l;
-          bool ok = s < b && s < total;
-          int j = -1;
-          if (ok) {
-            const Vec4<R> xj = T.sx[s];
-            j = real_as_idx(xj.w);
-            const R dx = xi.x - xj.x, dy_ = xi.y - xj.y, dz_ = xi.z - xj.z;
-            const R r2 = dx * dx + dy_ * dy_ + dz_ * dz_;
-            ok = (r2 <= rl2) && (j != p);
-            if (ok && e1 > e0) {
-              const int tj = tag[j];
-              for (int e = e0; e < e1; ++e) if (excl_list[e] == tj) { ok = false; break; }
-            }
+        const int a = T.rowoff[r] + T.celloff[r][lx];
+        int b = T.rowoff[r] + T.celloff[r][lx + 3];
+        b = b < total ? b : total;
+        for (int s = a; s < b; s += 4) {
+          // four staged candidates in flight; slots past the run read the far-away dummy
+          Vec4<R> xj[4]; R r2[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xj[u] = sx[(s + u < b) ? s + u : total];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const R dx = xi.x - xj[u].x, dy_ = xi.y - xj[u].y, dz_ = xi.z - xj[u].z;
+            r2[u] = dx * dx + dy_ * dy_ + dz_ * dz_;
           }
-          const unsigned long long m = __ballot(ok);
-          if (ok) {
-            const int pos = cnt + __popcll(m & lanemask_lt());
-            if (pos < S16) { row16[pos] = (unsigned short)s; if (row32) row32[pos] = j; }
-          }
-          cnt += __popcll(m);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) if (r2[u] <= rl2) hit(s + u, real_as_idx(xj[u].w));
         }
       }
-      // pad to a multiple of 8 slots with the far-away dummy slot (row reads are 16-byte)
-      const int c = cnt < S16 ? cnt : S16;
-      const int pad = (8 - (c & 7)) & 7;
-      if (l < pad) { row16[c + l] = (unsigned short)total; }
-      if (row32 && l < ((4 - (c & 3)) & 3)) row32[c + l] = p;
-      if (l == 0) { nn[p] = c; if (cnt > S16) atomicMax(&ctl->nl_overflow, cnt); }
+      // pad the last chunk with the far-away dummy slot (chunks are read whole)
+      const int real16 = cnt16;
+      if (real16 <= S16) while (cnt16 & 7) push((unsigned int)total);
+      nnh[hbase + q] = real16 < S16 ? real16 : S16;
+      if (real16 > S16) atomicMax(&ctl->nl_overflow, real16);
+      if (row32) {
+        const int c32 = cnt < S ? cnt : S;
+        for (int k = c32; k < ((c32 + 3) & ~3); ++k) row32[k] = p;
+        nn[p] = c32;
+        if (cnt > S) atomicMax(&ctl->nl_overflow, cnt);
+      }
     }
   }
 }
 
+// exclusive scan of the home-particle counts of all tiles -> geom[5] (base of the tile's region
+// in the transposed 16-bit list / count array); single block
+template <typename R>
+__global__ __launch_bounds__(1024) void k_tile_scan(int ntiles, TileLDS<R>* __restrict__ desc, const DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int w = threadIdx.x >> 6;
+  for (int base = 0; base < ntiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < ntiles ? desc[i].geom[4] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane_id() >= o) incl += t; }
+    if (lane_id() == 63) wsum[w] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) woff += wsum[k]; tot += wsum[k]; }
+    if (i < ntiles) desc[i].geom[5] = carry_s + woff + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+}
+
 // ---- pair forces on tiles --------------------------------------------------------------
-template <typename R, int TPP, bool ENERGY>
-__global__ __launch_bounds__(256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
-                                                    const int* __restrict__ cell_start, const unsigned short* __restrict__ nl16,
-                                                    const int* __restrict__ nn, int S16, Box<R> box,
-                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
-                                                    int ntypes, const Vec4<R>* __restrict__ tab, double* __restrict__ eout,
-                                                    double half_skin, DevCtl* ctl) {
+template <typename R, bool ENERGY, bool LJONLY>
+__device__ __forceinline__ void pair_accum(const PairCore<R> pc, const PairExt<R>* __restrict__ pext, int pidx,
+                                           const Vec4<R>* __restrict__ tab, R r2, R dx, R dy, R dz,
+                                           R& fx, R& fy, R& fz, double& e_lj, double& e_tab, double& vir) {
+  if (LJONLY && !ENERGY) {
+    const R r2i = rcp_r(r2), r6i = r2i * r2i * r2i;
+    R ff = r6i * (pc.lj1 * r6i - pc.lj2) * r2i;
+    ff = (r2 <= pc.rc2) ? ff * pc.kind : (R)0;   // kind (1 for LJ) keeps the read a single ds_read_b128 (b96 costs 2x the LDS cycles)
+    fx += ff * dx; fy += ff * dy; fz += ff * dz;
+  } else {
+    pair_term<R, ENERGY>(pc, pext, pidx, tab, r2, dx, dy, dz, fx, fy, fz, e_lj, e_tab, vir);
+  }
+}
+
+struct UniLJ { float rc2, lj1, lj2, pad; double drc2, dlj1, dlj2; };   // all listed pairs share one LJ parameter set
+
+// One workgroup per tile; TPP lanes per home particle (lane `sub` takes chunks sub, sub+TPP, ...).
+// MODE 0: general (type-pair table in LDS, tables allowed)  1: LJ/off pairs only, branch-free
+//      2: uniform LJ -- every listed pair has the same parameters (kernel arguments / SGPRs)
+template <typename R, int TPP, bool ENERGY, int BS, int MODE>
+__global__ __launch_bounds__(BS) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
+                                                   const TileLDS<R>* __restrict__ desc, const unsigned short* __restrict__ nl16,
+                                                   const int* __restrict__ nnh, int S16,
+                                                   const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
+                                                   int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
+                                                   double half_skin, DevCtl* ctl, int ablate, long long* __restrict__ dbg) {
+  constexpr bool LJONLY = MODE >= 1;
+  constexpr int NCH = TPP == 1 ? 5 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
+  long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
+  if (dbg) st0 = wall_clock64();
+  if (ablate == 4) return;   // diagnostic: dispatch cost only
   __shared__ TileLDS<R> T;
   __shared__ PairCore<R> spc[kMaxTypes * kMaxTypes];
-  if (threadIdx.x == 0) T.sx = dyn_lds<R>();
-  for (int k = threadIdx.x; k < ntypes * ntypes; k += blockDim.x) spc[k] = pcore[k];
+  CHEM_DYN_LDS(R);
+  if (MODE != 2) for (int k = threadIdx.x; k < ntypes * ntypes; k += BS) spc[k] = pcore[k];
   if (blockIdx.x == 0 && threadIdx.x == 0 && ctl->acc_maxdist > half_skin) ctl->skin_violation = 1;
-  const int tile = blockIdx.x;
+  const R u_rc2 = sizeof(R) == 4 ? (R)uni.rc2 : (R)uni.drc2, u_lj1 = sizeof(R) == 4 ? (R)uni.lj1 : (R)uni.dlj1,
+          u_lj2 = sizeof(R) == 4 ? (R)uni.lj2 : (R)uni.dlj2;
+  const int tile = xcd_remap(blockIdx.x, ntiles);
+  tile_load_desc<R>(T, desc, tile);
   __syncthreads();
-  tile_stage<R>(T, CAP, tile, x4, cell_start, box, 0, ctl);
-  const int nhome = T.geom[4];
+  if (ablate == 3) return;   // diagnostic: descriptor load only
+  if (dbg) st1 = wall_clock64();
+  const int nhome = T.geom[4], hbase = T.geom[5];
   const int slice = threadIdx.x / TPP, sub = threadIdx.x % TPP;
-  constexpr int NSL = 256 / TPP;
+  constexpr int NSL = BS / TPP;
+  const uint4* reg = reinterpret_cast<const uint4*>(nl16 + (size_t)hbase * S16);
+  // first pass's list/count loads are issued before the staging barrier so that their latency
+  // overlaps the stencil loads
+  int p = -1, cnt = 0, hslot = 0, qq = 0;
+  uint4 pkv[NCH];
+  auto locate = [&](int q) {
+    int sgi = 0;
+#pragma unroll
+    for (int k = 1; k < NHSEG; ++k) sgi += (q >= T.hoff[k]) ? 1 : 0;
+    const int inrun = q - T.hoff[sgi];
+    p = T.hstart[sgi] + inrun; qq = q;
+    const int hr = (sgi / HY + 1) * SY + (sgi % HY + 1);
+    hslot = T.rowoff[hr] + T.celloff[hr][1] + inrun;      // the home particle's own slot in the staged tile
+    cnt = nnh[hbase + q];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)                           // the tile's region is always allocated: safe before cnt is known
+      pkv[c] = (sub + c * TPP) * 8 < S16 ? nt_load_u4(&reg[(size_t)(sub + c * TPP) * nhome + q]) : make_uint4(0, 0, 0, 0);
+  };
+  if (slice < nhome) locate(slice);
+  if (ablate != 2) tile_fill<R, BS>(T, sx, CAP, x4, 0);
+  __syncthreads();
+  if (ablate == 1) return;   // diagnostic: staging only
+  if (dbg) st2 = wall_clock64();
   double e_lj = 0, e_tab = 0, vir = 0;
   for (int q0 = 0; q0 < nhome; q0 += NSL) {
     const int q = q0 + slice;
     R fx = 0, fy = 0, fz = 0;
-    int p = -1;
-    if (q < nhome) {
-      int sgi = 0;
-#pragma unroll
-      for (int k = 1; k < NHSEG; ++k) sgi += (q >= T.hoff[k]) ? 1 : 0;
-      p = T.hstart[sgi] + (q - T.hoff[sgi]);
-      const Vec4<R> xi = x4[p];
+    if (q0 > 0) { p = -1; if (q < nhome) locate(q); }
+    if (p >= 0) {
+      const Vec4<R> xi = sx[hslot];
       const int pbase = (int)xi.w * ntypes;
-      const int cnt = nn[p];
-      const uint4* row = reinterpret_cast<const uint4*>(nl16 + (size_t)p * S16);
-      for (int k = sub * 8; k < cnt; k += TPP * 8) {
-        const uint4 pk = row[k >> 3];
+      auto do_chunk = [&](const uint4 pk) {
         const unsigned int wds[4] = {pk.x, pk.y, pk.z, pk.w};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int s = (wds[u >> 1] >> ((u & 1) * 16)) & 0xffff;
-          const Vec4<R> xj = T.sx[s];
-          const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-          const R r2 = dx * dx + dy * dy + dz * dz;
-          const int pidx = pbase + (int)xj.w;
-          pair_term<R, ENERGY>(spc[pidx], pext, pidx, tab, r2, dx, dy, dz, fx, fy, fz, e_lj, e_tab, vir);
+        for (int h = 0; h < 2; ++h) {
+          Vec4<R> xs[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) xs[u] = sx[(wds[2 * h + (u >> 1)] >> ((u & 1) * 16)) & 0xffff];   // 4 LDS gathers in flight
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const Vec4<R> xj = xs[u];
+            const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+            const R r2 = dx * dx + dy * dy + dz * dz;
+            if (MODE == 2 && !ENERGY) {
+              const R r2i = rcp_r(r2), r6i = r2i * r2i * r2i;
+              R ff = r6i * (u_lj1 * r6i - u_lj2) * r2i;
+              ff = (r2 <= u_rc2) ? ff : (R)0;
+              fx += ff * dx; fy += ff * dy; fz += ff * dz;
+            } else {
+              const int pidx = pbase + (int)xj.w;
+              pair_accum<R, ENERGY, LJONLY>(spc[pidx], pext, pidx, tab, r2, dx, dy, dz, fx, fy, fz, e_lj, e_tab, vir);
+            }
+          }
         }
-      }
+      };
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) if ((sub + c * TPP) * 8 < cnt) do_chunk(pkv[c]);
+      for (int c = sub + NCH * TPP; c * 8 < cnt; c += TPP) do_chunk(reg[(size_t)c * nhome + qq]);   // long rows
     }
     if (TPP > 1) {
 #pragma unroll
@@ -756,14 +960,19 @@ __global__ __launch_bounds__(256) void k_pair_tiles(int ntiles, int CAP, const V
     }
     if (p >= 0 && sub == 0) f4[p] = mk4<R>(fx, fy, fz, (R)0);
   }
+  if (dbg && threadIdx.x == 0) {   // diagnostic build path only: per-block phase stamps (100 MHz wall clock)
+    st3 = wall_clock64();
+    long long* o = dbg + 6 * (size_t)blockIdx.x;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = 0; o[5] = tile;
+  }
   if (ENERGY) {
-    __shared__ double red[3][4];
+    __shared__ double red[3][BS / 64];
     for (int o = 32; o > 0; o >>= 1) { e_lj += __shfl_xor(e_lj, o); e_tab += __shfl_xor(e_tab, o); vir += __shfl_xor(vir, o); }
     if (lane_id() == 0) { red[0][threadIdx.x >> 6] = e_lj; red[1][threadIdx.x >> 6] = e_tab; red[2][threadIdx.x >> 6] = vir; }
     __syncthreads();
     if (threadIdx.x == 0) {
       double a = 0, b = 0, c = 0;
-      for (int k = 0; k < 4; ++k) { a += red[0][k]; b += red[1][k]; c += red[2][k]; }
+      for (int k = 0; k < BS / 64; ++k) { a += red[0][k]; b += red[1][k]; c += red[2][k]; }
       eout[3 * blockIdx.x + 0] = 0.5 * a; eout[3 * blockIdx.x + 1] = 0.5 * b; eout[3 * blockIdx.x + 2] = 0.5 * c;
     }
   }
