@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <tuple>
 
@@ -49,6 +50,13 @@ template <typename T> struct DBuf {
   }
 };
 
+static const bool g_trace = getenv("CHEM_TRACE") != nullptr;
+struct Trace {
+  double t; const char* what;
+  Trace(const char* w) : t(now_s()), what(w) {}
+  void lap(const char* tag) { if (g_trace) { double n = now_s(); fprintf(stderr, "[chem trace] %s/%s %.3f ms\n", what, tag, 1e3 * (n - t)); t = n; } }
+};
+
 static inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------
@@ -64,8 +72,10 @@ struct Ctx {
   bool react_init = false, react_on = false;
   int interval = 0, nearest = 1; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
-  std::vector<chem_event> events;
-  size_t events_sorted = 0;  // prefix of `events` already in canonical order
+  std::vector<chem_event> events;   // expanded, canonical order (filled lazily from raw_events)
+  struct RawEvents { int64_t step; std::vector<int32_t> a, b, r; std::vector<double> d2; };   // SoA copy of the device records
+  std::vector<RawEvents> raw_events;  // one block per reaction step, device order
+  int64_t n_events = 0;
   int64_t step = 0;
   bool resort = true;
   bool geom_dirty = true, particles_dirty = true, pair_dirty = true, bonded_dirty = true, excl_dirty = true, labels_dirty = true;
@@ -94,6 +104,7 @@ template <typename R> struct CtxT : Ctx {
   using V4 = Vec4<R>;
   int pair_bs = 512;
   bool lj_only = true;
+  bool state_mirror_stale = false;   // top.state lags the device after reaction steps
   int tile_cap = 0;       // LDS slots of one staged tile (dynamic LDS)
   size_t tile_lds_bytes() const { return (size_t)(tile_cap + 2) * sizeof(V4) + 16; }
   hipStream_t stream = nullptr;
@@ -106,6 +117,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<unsigned short> nl16;
   DBuf<TileLDS<R>> tdesc;
   DBuf<long long> dbgbuf; bool dbg_on = false;
+  Candidate* pin_ev = nullptr; size_t pin_ev_cap = 0;   // pinned host staging for reaction events
   int S = 0;
   bool use_tiles = false, want32 = false;   // int32 list only built on demand (reaction steps, diagnostics)
   ActMask act{}; UniLJ uni{}; bool uniform_lj = false;
@@ -129,6 +141,7 @@ template <typename R> struct CtxT : Ctx {
   CtxT() { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
   ~CtxT() override {
     for (auto e : ev) (void)hipEventDestroy(e);
+    if (pin_ev) (void)hipHostFree(pin_ev);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void sync() override { HIPCHK(hipStreamSynchronize(stream)); }
@@ -222,6 +235,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void upload_labels() {
+    if (state_mirror_stale) { std::vector<int> hs; state.download(hs, n, stream); top.state.assign(hs.begin(), hs.end()); state_mirror_stale = false; }
     state.upload(top.state, stream); res_id.upload(top.res_id, stream); mol_id.upload(top.mol_id, stream);
     HIPCHK(hipStreamSynchronize(stream));
     labels_dirty = false;
@@ -516,11 +530,14 @@ template <typename R> struct CtxT : Ctx {
     }
     HIPCHK(hipMemcpyAsync(rs_dev.p, &rs, sizeof(ReactSet), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    Trace tr("react");
     ensure_list32();
+    tr.lap("list32");
     set_ctl_field(&DevCtl::cand_count, 0);
     hipLaunchKernelGGL(k_react_scan<R>, dim3(cdiv((long long)n * 8, 256)), dim3(256), 0, stream, n, x4.p, tag.p, nlist.p, nn.p, S, state.p,
                        res_id.p, mol_id.p, boxd, rs_dev.p, cand.p, cand_cap, ctl.p);
     DevCtl h = read_ctl();
+    tr.lap("scan");
     if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
     const int nc = h.cand_count;
     if (nc == 0) { tm.reaction_wall_s += now_s() - t0; return; }
@@ -536,20 +553,33 @@ template <typename R> struct CtxT : Ctx {
     hipLaunchKernelGGL(k_fill<int>, dim3(npb), dim3(256), 0, stream, asA.p, -1, (size_t)n);
     hipLaunchKernelGGL(k_fill<int>, dim3(npb), dim3(256), 0, stream, asB.p, -1, (size_t)n);
     hipLaunchKernelGGL(k_res_index, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, asA.p, asB.p);
+    if (g_trace) { HIPCHK(hipStreamSynchronize(stream)); tr.lap("uniqueAB"); }
     int* sin = st0.p; int* sout = st1.p;
-    for (int round = 0; round < 100000; ++round) {
-      set_ctl_field(&DevCtl::alive, 0);
-      hipLaunchKernelGGL(k_res_round, dim3(ncb), dim3(256), 0, stream, nc, cand.p, sin, sout, asA.p, asB.p, nearest, ctl.p);
-      std::swap(sin, sout);
+    for (int batch = 0; batch < 20000; ++batch) {
+      // `alive` is only meaningful for the last round of a batch: extra rounds on a finished
+      // matching are no-ops, so rounds are enqueued 8 at a time between host checks
+      for (int rr = 0; rr < 8; ++rr) {
+        if (rr == 7) HIPCHK(hipMemsetAsync(&ctl.p->alive, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_res_round, dim3(ncb), dim3(256), 0, stream, nc, cand.p, sin, sout, asA.p, asB.p, nearest, ctl.p);
+        std::swap(sin, sout);
+      }
       if (read_ctl().alive == 0) break;
     }
+    if (g_trace) { fprintf(stderr, "[chem trace] candidates %d\n", nc); tr.lap("rounds"); }
     HIPCHK(hipMemsetAsync(evcount.p, 0, sizeof(int), stream));
     hipLaunchKernelGGL(k_react_apply<R>, dim3(ncb), dim3(256), 0, stream, nc, cand.p, sin, ras, state.p, rtag.p, x4.p, v4.p, evout.p, evcount.p);
     int nev = 0;
     HIPCHK(hipMemcpyAsync(&nev, evcount.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    std::vector<Candidate> hev;
-    evout.download(hev, (size_t)nev, stream);
+    if ((size_t)nev > pin_ev_cap) {
+      if (pin_ev) (void)hipHostFree(pin_ev);
+      pin_ev_cap = std::max<size_t>((size_t)nev * 2, 1 << 16);
+      HIPCHK(hipHostMalloc((void**)&pin_ev, pin_ev_cap * sizeof(Candidate), hipHostMallocDefault));
+    }
+    if (nev) HIPCHK(hipMemcpyAsync(pin_ev, evout.p, (size_t)nev * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<Candidate> hev(pin_ev, pin_ev + nev);
+    tr.lap("resolve+apply+download");
     // Host mirrors + topology.  Only bond-forming events need the canonical order now (it fixes
     // the order of the bond lists); the event log itself is put in canonical order lazily
     // by chem_get_events.
@@ -560,22 +590,31 @@ template <typename R> struct CtxT : Ctx {
     }
     std::vector<std::pair<int32_t, int32_t>> newbonds;
     bool types_changed = false;
+    {
+      Ctx::RawEvents blk; blk.step = step;
+      blk.a.resize(hev.size()); blk.b.resize(hev.size()); blk.r.resize(hev.size()); blk.d2.resize(hev.size());
+      for (size_t k = 0; k < hev.size(); ++k) { blk.a[k] = hev[k].a; blk.b[k] = hev[k].b; blk.r[k] = hev[k].r; blk.d2[k] = hev[k].d2; }
+      raw_events.push_back(std::move(blk)); n_events += (int64_t)hev.size();
+    }
     for (auto& e : hev) {
       const chem_reaction_desc& d = reactions[e.r];
-      top.state[e.a] += d.delta_1; top.state[e.b] += d.delta_2;
+      // host mirrors: only what the host itself needs later (types for bonded-slot resolution and
+      // the topology manager); chemical states live on the device
       if (d.new_type_1 >= 0 && d.new_type_1 != top.type[e.a]) { top.type[e.a] = d.new_type_1; top.mass[e.a] = d.new_mass_1; top.q[e.a] = d.new_q_1; types_changed = true; }
       if (d.new_type_2 >= 0 && d.new_type_2 != top.type[e.b]) { top.type[e.b] = d.new_type_2; top.mass[e.b] = d.new_mass_2; top.q[e.b] = d.new_q_2; types_changed = true; }
-      events.push_back(chem_event{step, top.id[e.a], top.id[e.b], e.r, 0, e.d2});
       if (!d.is_virtual) {
         int32_t t[2] = {e.a, e.b};
         if (top.list_insert(top.lists[d.bond_list], t)) newbonds.emplace_back(e.a, e.b);
       }
     }
+    state_mirror_stale = true;
+    tr.lap("host events");
     if (!newbonds.empty()) {
       std::vector<int32_t> touched;
       top.on_new_bonds(newbonds, touched);
+      tr.lap("on_new_bonds");
       res_id.upload(top.res_id, stream); mol_id.upload(top.mol_id, stream);
-      upload_bonded(); upload_excl();
+      upload_bonded(); tr.lap("upload_bonded"); upload_excl(); tr.lap("upload_excl");
       resort = true;
       set_ctl_field(&DevCtl::force_rebuild, 1);
     }
@@ -778,7 +817,7 @@ int chem_set_particles(chem_ctx* ctx, int64_t n, const int64_t* id, const int32_
   for (int64_t i = 1; i < n; ++i) if (id[i] <= id[i - 1]) { sorted = false; break; }
   if (!sorted) std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return id[a] < id[b]; });
   t.n = n; t.id.resize(n); t.type.resize(n); t.state.resize(n); t.res_id.resize(n); t.mol_id.resize(n); t.mass.resize(n); t.q.resize(n);
-  t.graph.assign(n, {}); t.excl.assign(n, {}); t.n_excl_pairs = 0; t.id2tag.clear();
+  t.graph.assign(n, TagRow()); t.excl.assign(n, TagRow()); t.n_excl_pairs = 0; t.id2tag.clear();
   for (auto& l : t.lists) { l.ent.clear(); l.seen.clear(); }
   c.pos0.resize(3 * n); c.vel0.assign(3 * n, 0.0);
   t.contiguous = true; t.id0 = id[order[0]];
@@ -794,7 +833,7 @@ int chem_set_particles(chem_ctx* ctx, int64_t n, const int64_t* id, const int32_
   }
   if (!t.contiguous) for (int64_t k = 0; k < n; ++k) t.id2tag[t.id[k]] = (int32_t)k;
   c.particles_dirty = c.pair_dirty = c.bonded_dirty = c.excl_dirty = c.labels_dirty = true; c.resort = true;
-  c.step = 0; c.events.clear(); c.events_sorted = 0;
+  c.step = 0; c.events.clear(); c.raw_events.clear(); c.n_events = 0;
   return 0;
   API_END(ctx)
 }
@@ -988,17 +1027,20 @@ int64_t chem_get_state(chem_ctx* ctx, int what, void* out, int64_t cap) {
 
 int64_t chem_get_events(chem_ctx* ctx, chem_event* out, int64_t cap) {
   API_BEGIN
-  const int64_t n = (int64_t)CTX.events.size();
+  Ctx& c = CTX;
+  const int64_t n = c.n_events;
   if (!out) return n;
   REQUIRE(cap >= n, CHEM_ENOSPC, "get_events: capacity");
-  if (CTX.events_sorted < CTX.events.size()) {   // canonical order: (step, min id, max id)
-    std::sort(CTX.events.begin() + CTX.events_sorted, CTX.events.end(), [](const chem_event& p, const chem_event& q) {
-      return std::make_tuple(p.step, std::min(p.id_a, p.id_b), std::max(p.id_a, p.id_b)) <
-             std::make_tuple(q.step, std::min(q.id_a, q.id_b), std::max(q.id_a, q.id_b));
+  // expand the raw per-step blocks and put each into canonical order: (step, min id, max id)
+  for (auto& blk : c.raw_events) {
+    const size_t m = blk.a.size(), first = c.events.size();
+    for (size_t k = 0; k < m; ++k) c.events.push_back(chem_event{blk.step, c.top.id[blk.a[k]], c.top.id[blk.b[k]], blk.r[k], 0, blk.d2[k]});
+    std::sort(c.events.begin() + first, c.events.end(), [](const chem_event& p, const chem_event& q) {
+      return std::make_pair(std::min(p.id_a, p.id_b), std::max(p.id_a, p.id_b)) < std::make_pair(std::min(q.id_a, q.id_b), std::max(q.id_a, q.id_b));
     });
-    CTX.events_sorted = CTX.events.size();
   }
-  std::copy(CTX.events.begin(), CTX.events.end(), out);
+  c.raw_events.clear();
+  std::copy(c.events.begin(), c.events.end(), out);
   return n;
   API_END(ctx)
 }

@@ -46,10 +46,50 @@ inline TupleKey tuple_key(const int32_t* t, int arity) {
   return {((uint64_t)(uint32_t)c[0] << 32) | (uint32_t)c[1], ((uint64_t)(uint32_t)c[2] << 32) | (uint32_t)c[3]};
 }
 
+// open-addressing set of tuple keys (no allocation per insert)
+struct TupleSet {
+  std::vector<TupleKey> slot; size_t used = 0;
+  static bool empty_key(const TupleKey& k) { return k.a == ~0ull && k.b == ~0ull; }
+  void clear() { slot.clear(); used = 0; }
+  void grow() {
+    std::vector<TupleKey> old; old.swap(slot);
+    slot.assign(old.empty() ? 1024 : old.size() * 2, TupleKey{~0ull, ~0ull}); used = 0;
+    for (auto& k : old) if (!empty_key(k)) insert(k);
+  }
+  bool insert(const TupleKey& k) {
+    if ((used + 1) * 10 >= slot.size() * 7) grow();
+    size_t m = slot.size() - 1, i = TupleKeyHash()(k) & m;
+    while (!empty_key(slot[i])) { if (slot[i] == k) return false; i = (i + 1) & m; }
+    slot[i] = k; ++used; return true;
+  }
+};
+
+// sorted small set of tags with inline storage for the common case (<= 6 partners): the bond
+// graph and the exclusion rows of 10^6 particles would otherwise cost one heap block each
+struct TagRow {
+  int32_t inl[6]; int32_t n = 0; std::vector<int32_t>* big = nullptr;
+  TagRow() {}
+  TagRow(const TagRow& o) : n(o.n), big(o.big ? new std::vector<int32_t>(*o.big) : nullptr) { std::copy(o.inl, o.inl + 6, inl); }
+  TagRow& operator=(const TagRow& o) { if (this != &o) { delete big; n = o.n; big = o.big ? new std::vector<int32_t>(*o.big) : nullptr; std::copy(o.inl, o.inl + 6, inl); } return *this; }
+  ~TagRow() { delete big; }
+  const int32_t* begin() const { return big ? big->data() : inl; }
+  const int32_t* end() const { return begin() + n; }
+  size_t size() const { return (size_t)n; }
+  void clear() { delete big; big = nullptr; n = 0; }
+  bool insert(int32_t x) {
+    int32_t* b = big ? big->data() : inl;
+    int32_t* it = std::lower_bound(b, b + n, x);
+    if (it != b + n && *it == x) return false;
+    if (!big && n < 6) { std::copy_backward(it, b + n, b + n + 1); *it = x; ++n; return true; }
+    if (!big) { big = new std::vector<int32_t>(inl, inl + n); }
+    big->insert(big->begin() + (it - b), x); ++n; return true;
+  }
+};
+
 struct HostList {
   int arity = 2, kind = 0, by_types = 0;
   std::vector<int32_t> ent;  // arity tags per entry
-  std::unordered_set<TupleKey, TupleKeyHash> seen;
+  TupleSet seen;
   bool has_plain = false;
   std::array<double, CHEM_MAX_POT_PARAMS> plain{};
   std::map<std::array<int, 4>, std::array<double, CHEM_MAX_POT_PARAMS>> typed;
@@ -75,8 +115,8 @@ struct HostTopology {
   std::unordered_map<int64_t, int32_t> id2tag;
   std::vector<int32_t> type, state, res_id, mol_id;
   std::vector<double> mass, q;
-  std::vector<std::vector<int32_t>> graph;  // sorted adjacency (bond graph)
-  std::vector<std::vector<int32_t>> excl;   // sorted, symmetric
+  std::vector<TagRow> graph;  // sorted adjacency (bond graph)
+  std::vector<TagRow> excl;   // sorted, symmetric
   std::vector<HostList> lists;
   int64_t n_excl_pairs = 0;
 
@@ -86,12 +126,7 @@ struct HostTopology {
     return it == id2tag.end() ? -1 : it->second;
   }
 
-  static bool sorted_insert(std::vector<int32_t>& v, int32_t x) {
-    auto it = std::lower_bound(v.begin(), v.end(), x);
-    if (it != v.end() && *it == x) return false;
-    v.insert(it, x);
-    return true;
-  }
+  static bool sorted_insert(TagRow& v, int32_t x) { return v.insert(x); }
 
   bool exclude(int32_t a, int32_t b) {
     if (a == b) return false;
@@ -102,7 +137,7 @@ struct HostTopology {
   }
 
   bool list_insert(HostList& l, const int32_t* t) {
-    if (!l.seen.insert(tuple_key(t, l.arity)).second) return false;
+    if (!l.seen.insert(tuple_key(t, l.arity))) return false;
     l.ent.insert(l.ent.end(), t, t + l.arity);
     return true;
   }
@@ -112,18 +147,24 @@ struct HostTopology {
   // relabel the bonded cluster containing a (a-b already linked).  Labels: res_id takes
   // min(res_id[a],res_id[b]) (reaction.cfg: "the residue id will be transfered"), mol_id the
   // lowest tag of the cluster.  `touched` collects tags whose labels changed.
+  std::vector<uint32_t> visit_stamp;   // flood-fill marks (epoch stamped, no per-call allocation)
+  uint32_t visit_epoch = 0;
+  std::vector<int32_t> flood_stack;
+
   void merge_cluster(int32_t a, int32_t b, bool relabel_res, std::vector<int32_t>& touched) {
     const int32_t new_res = std::min(res_id[a], res_id[b]);
     const int32_t new_mol = std::min(mol_id[a], mol_id[b]);
-    std::vector<int32_t> stack{a};
-    std::unordered_set<int32_t> vis{a};
-    while (!stack.empty()) {
-      int32_t p = stack.back(); stack.pop_back();
+    if (visit_stamp.size() != (size_t)n) { visit_stamp.assign((size_t)n, 0); visit_epoch = 0; }
+    if (++visit_epoch == 0) { std::fill(visit_stamp.begin(), visit_stamp.end(), 0); visit_epoch = 1; }
+    flood_stack.clear(); flood_stack.push_back(a);
+    visit_stamp[a] = visit_epoch;
+    while (!flood_stack.empty()) {
+      int32_t p = flood_stack.back(); flood_stack.pop_back();
       bool ch = false;
       if (relabel_res && res_id[p] != new_res) { res_id[p] = new_res; ch = true; }
       if (mol_id[p] != new_mol) { mol_id[p] = new_mol; ch = true; }
       if (ch) touched.push_back(p);
-      for (int32_t nb : graph[p]) if (vis.insert(nb).second) stack.push_back(nb);
+      for (int32_t nb : graph[p]) if (visit_stamp[nb] != visit_epoch) { visit_stamp[nb] = visit_epoch; flood_stack.push_back(nb); }
     }
   }
 
