@@ -103,6 +103,7 @@ SIGNATURES = {
     "get_verlet_pairs": (_i64, [_P, _pi64, _i64]),
     "observe": (_i, [_P, C.POINTER(Obs)]),
     "get_timers": (_i, [_P, C.POINTER(Timers)]),
+    "set_option": (_i, [_P, C.c_char_p, _d]),
 }
 
 # entry points that only the product library exports
@@ -111,7 +112,6 @@ PRODUCT_ONLY = {
     "abi_version": (_i, []),
     "device_sync": (_i, [_P]),
     "set_nlist_capacity": (_i, [_P, _i]),
-    "set_option": (_i, [_P, C.c_char_p, _d]),
     "comm_unique_id": (_i, [C.c_char_p]),
     "comm_init": (_i, [_P, _i, _i, C.POINTER(C.c_int), C.c_char_p]),
 }

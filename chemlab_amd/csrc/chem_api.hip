@@ -84,6 +84,7 @@ struct Ctx {
   int opt_time_pair = 0;    // HIP-event timing of every pair-force launch
   int opt_fuse = 1;         // fused integrate2+integrate1
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
+  int opt_criterion = 0;     // 1: rebuild when max |x - x(last build)| > skin/2 ; 0: reference's accumulated per-step maxima
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
   chem_timers tm{};
@@ -109,7 +110,7 @@ template <typename R> struct CtxT : Ctx {
   size_t tile_lds_bytes() const { return (size_t)(tile_cap + 2) * sizeof(V4) + 16; }
   hipStream_t stream = nullptr;
   int n = 0;
-  DBuf<V4> x4, v4, f4, x4o, v4o, tab;
+  DBuf<V4> x4, v4, f4, x4o, v4o, tab, x0;
   DBuf<int> tag, tago, rtag, state, res_id, mol_id;
   DBuf<int4> img4, img4o;
   DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
@@ -217,7 +218,8 @@ template <typename R> struct CtxT : Ctx {
       ht[t] = t;
     }
     x4.upload(hx, stream); v4.upload(hv, stream); tag.upload(ht, stream); rtag.upload(ht, stream); img4.upload(hi, stream);
-    f4.alloc(n); x4o.alloc(n); v4o.alloc(n); tago.alloc(n); img4o.alloc(n);
+    f4.alloc(n); x4o.alloc(n); v4o.alloc(n); tago.alloc(n); img4o.alloc(n); x0.alloc(n);
+    HIPCHK(hipMemcpyAsync(x0.p, x4.p, sizeof(V4) * n, hipMemcpyDeviceToDevice, stream));
     HIPCHK(hipMemsetAsync(f4.p, 0, sizeof(V4) * n, stream));
     cell_of.alloc(n); slot_of.alloc(n); perm.alloc(n); nn.alloc(n);
     HIPCHK(hipMemsetAsync(nn.p, 0, sizeof(int) * n, stream));
@@ -337,7 +339,7 @@ template <typename R> struct CtxT : Ctx {
     hipLaunchKernelGGL(k_place, dim3(nb), dim3(256), 0, stream, n, cell_of.p, slot_of.p, cell_start.p, perm.p, c);
     hipLaunchKernelGGL(k_sort_gather<R>, dim3(std::min(cdiv(box.ncell, 4), 2048)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p,
                        x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
-    hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, n, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, c);
+    hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, n, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, x0.p, c);
     const R rl2 = (R)((rc + skin) * (rc + skin));
     if (use_tiles) {
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c);
@@ -353,7 +355,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void decide_and_rebuild() {
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin, opt_criterion);
     launch_rebuild_chain();
   }
 
@@ -441,11 +443,11 @@ template <typename R> struct CtxT : Ctx {
     const int nb = cdiv(n, 256);
     LangevinP<R> lp = lang_params(istep, phase);
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p, opt_criterion ? x0.p : (const V4*)nullptr);
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p, opt_criterion ? x0.p : (const V4*)nullptr);
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p, opt_criterion ? x0.p : (const V4*)nullptr);
   }
 
   void check_flags() {
@@ -1082,6 +1084,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else if (k == "pair_block") { const int v = (int)value; REQUIRE(v == 256 || v == 512 || v == 1024, CHEM_EINVAL, "pair_block must be 256, 512 or 1024"); CTX.set_pair_bs(v); }
   else if (k == "ablate") CTX.opt_ablate = (int)value;
+  else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; }
   else if (k == "debug_stamps") CTX.debug_enable((int)value);
   else if (k == "skip_inactive_pairs") { CTX.opt_skip_inactive = value != 0; CTX.pair_dirty = true; }
   else throw ChemError(CHEM_EINVAL, "unknown option " + k);

@@ -102,10 +102,13 @@ __device__ __forceinline__ void langevin_force(const LangevinP<R>& lp, int tag, 
 // mode bits: 1 = second half-kick (integrate2), 2 = first half-kick + drift (integrate1),
 // 3 = fused integrate2(step s) + integrate1(step s+1); 4 = add Langevin force to f first
 // (thermalize at aftCalcF) and, when mode has no drift..., store f_total back.
+// x0 != nullptr: rebuild criterion "displacement" (max |x - x_at_last_build|^2); nullptr: the
+// reference's accumulated per-step maxima (max |dt v|^2 of this step)
 template <typename R, int MODE, bool LANG, bool STOREF>
 __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
-                                                    R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax) {
+                                                    R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax,
+                                                    const Vec4<R>* __restrict__ x0) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   R d2 = 0;
   if (i < n) {
@@ -122,6 +125,7 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
       R dx = dt * v.x, dy = dt * v.y, dz = dt * v.z;
       x.x += dx; x.y += dy; x.z += dz;
       x4[i] = x;
+      if (x0) { const Vec4<R> o = x0[i]; dx = x.x - o.x; dy = x.y - o.y; dz = x.z - o.z; }
       d2 = dx * dx + dy * dy + dz * dz;
     }
     v4[i] = v;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
 // one block: fold the step's per-block max displacement into the accumulated distance and
 // decide whether the Verlet list must be rebuilt (VelocityVerlet::run)
 template <typename R>
-__global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned long long* __restrict__ blockmax, int nblk, double half_skin) {
+__global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned long long* __restrict__ blockmax, int nblk, double half_skin, int criterion) {
   unsigned long long m = 0;
   for (int k = threadIdx.x; k < nblk; k += 1024) { unsigned long long b = blockmax[k]; blockmax[k] = 0ull; m = b > m ? b : m; }
   for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned l
   if (threadIdx.x == 0) {
     for (int k = 1; k < 16; ++k) m = wm[k] > m ? wm[k] : m;
     const double m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
-    double acc = ctl->acc_maxdist + sqrt(m2);
+    double acc = criterion ? sqrt(m2) : ctl->acc_maxdist + sqrt(m2);
     const int need = (acc > half_skin) || ctl->force_rebuild;
     if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
     ctl->acc_maxdist = acc;
@@ -272,10 +276,12 @@ __global__ __launch_bounds__(256) void k_copyback(int n, const Vec4<R>* __restri
                                                   const int* __restrict__ tago,
                                                   const int4* __restrict__ img4o, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                   int* __restrict__ tag, int4* __restrict__ img4,
-                                                  int* __restrict__ rtag, const DevCtl* ctl) {
+                                                  int* __restrict__ rtag, Vec4<R>* __restrict__ x0, const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-    x4[k] = x4o[k]; v4[k] = v4o[k]; img4[k] = img4o[k];
+    const Vec4<R> xk = x4o[k];
+    x4[k] = xk; if (x0) x0[k] = xk;
+    v4[k] = v4o[k]; img4[k] = img4o[k];
     int t = tago[k]; tag[k] = t; rtag[t] = k;
   }
 }
@@ -788,23 +794,39 @@ __global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const V
           if (row32) { if (cnt < S) row32[cnt] = j; ++cnt; }
         }
       };
+      // Two passes per x-run segment of <= 64 staged candidates:
+      //  1. distance tests only, results OR-ed into a 64-bit per-lane hit mask (no branches);
+      //  2. the few hits (~15 %) are peeled off the mask one by one for the type / exclusion /
+      //     activity filters and the chunked store.
+      // The branchy hit handling no longer sits in the loop that runs 475 times per particle.
       for (int dz = 0; dz < 3; ++dz) for (int dy = 0; dy < 3; ++dy) {
         const int r = (lz + dz) * SY + (ly + dy);
         const int a = T.rowoff[r] + T.celloff[r][lx];
         int b = T.rowoff[r] + T.celloff[r][lx + 3];
         b = b < total ? b : total;
-        for (int s = a; s < b; s += 4) {
-          // four staged candidates in flight; slots past the run read the far-away dummy
-          Vec4<R> xj[4]; R r2[4];
+        for (int s0 = a; s0 < b; s0 += 64) {
+          const int len = (b - s0) < 64 ? (b - s0) : 64;
+          unsigned int mlo = 0, mhi = 0;
+          for (int k = 0; k < len; k += 4) {
+            Vec4<R> xj[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xj[u] = sx[(s + u < b) ? s + u : total];
+            for (int u = 0; u < 4; ++u) xj[u] = sx[(k + u < len) ? s0 + k + u : total];   // past the run: far-away dummy
+            unsigned int bits = 0;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const R dx = xi.x - xj[u].x, dy_ = xi.y - xj[u].y, dz_ = xi.z - xj[u].z;
-            r2[u] = dx * dx + dy_ * dy_ + dz_ * dz_;
+            for (int u = 0; u < 4; ++u) {
+              const R dx = xi.x - xj[u].x, dy_ = xi.y - xj[u].y, dz_ = xi.z - xj[u].z;
+              const R r2 = dx * dx + dy_ * dy_ + dz_ * dz_;
+              bits |= (r2 <= rl2) ? (1u << u) : 0u;
+            }
+            if (k < 32) mlo |= bits << k; else mhi |= bits << (k - 32);
           }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) if (r2[u] <= rl2) hit(s + u, real_as_idx(xj[u].w));
+          unsigned long long m = ((unsigned long long)mhi << 32) | mlo;
+          while (m) {
+            const int k = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int s = s0 + k;
+            hit(s, real_as_idx(sx[s].w));
+          }
         }
       }
       // pad the last chunk with the far-away dummy slot (chunks are read whole)
@@ -869,7 +891,7 @@ struct UniLJ { float rc2, lj1, lj2, pad; double drc2, dlj1, dlj2; };   // all li
 // MODE 0: general (type-pair table in LDS, tables allowed)  1: LJ/off pairs only, branch-free
 //      2: uniform LJ -- every listed pair has the same parameters (kernel arguments / SGPRs)
 template <typename R, int TPP, bool ENERGY, int BS, int MODE>
-__global__ __launch_bounds__(BS) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
+__global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
                                                    const TileLDS<R>* __restrict__ desc, const unsigned short* __restrict__ nl16,
                                                    const int* __restrict__ nnh, int S16,
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,

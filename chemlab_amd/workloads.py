@@ -206,6 +206,8 @@ def trimer_melt(n_mol=200, rho=0.27, rc=2.5, skin=0.4, dt=0.0025, kT=1.0, gamma=
 def apply(spec, eng, thermostat=True, reactions=True):
     """Issue the set-up calls for `spec` on Engine `eng`; returns dict of list handles."""
     eng.set_box(spec["box"])
+    if "rebuild_criterion" in spec:
+        eng.set_option("rebuild_criterion", spec["rebuild_criterion"])
     eng.set_cutoff(spec["rc"], spec["skin"])
     eng.set_dt(spec["dt"])
     eng.set_particles(spec["ids"], spec["types"], spec["pos"], spec["mass"], vel=spec.get("vel"),

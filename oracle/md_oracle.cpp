@@ -99,6 +99,8 @@ struct Orc {
   int64_t step = 0;
   bool resort = true;
   double maxdist = 0;
+  int criterion = 0;            // 0: accumulated per-step maxima (ESPResSo++), 1: max true displacement since the last build
+  std::vector<Vec3> x0;         // positions at the last list build (criterion 1)
   std::vector<std::pair<int32_t, int32_t>> pairs;  // half Verlet list
   int64_t rebuilds = 0, reaction_steps = 0;
   double e_lj = 0, e_tab = 0, virial = 0;
@@ -176,6 +178,7 @@ static void build_pairs(Orc& o) {
         }
   }
   std::sort(o.pairs.begin(), o.pairs.end());
+  o.x0 = o.x;
   o.maxdist = 0;
   o.resort = false;
   o.rebuilds++;
@@ -467,10 +470,11 @@ static void run(Orc& o, int64_t nsteps) {
       o.v[i] = o.v[i] + hm * o.f[i];
       Vec3 dx = o.dt * o.v[i];
       o.x[i] = o.x[i] + dx;
+      if (o.criterion == 1) dx = o.x[i] - o.x0[i];
       double d2 = dx.x * dx.x + dx.y * dx.y + dx.z * dx.z;
       if (d2 > max2) max2 = d2;
     }
-    o.maxdist += std::sqrt(max2);
+    if (o.criterion == 1) o.maxdist = std::sqrt(max2); else o.maxdist += std::sqrt(max2);
     if (o.maxdist > 0.5 * o.skin || o.resort) build_pairs(o);
     update_forces(o, o.step, 1);
     for (int64_t i = 0; i < o.n; ++i) o.v[i] = o.v[i] + (0.5 * o.dt / o.mass[i]) * o.f[i];
@@ -626,6 +630,12 @@ int orc_topology_register(void* c, int arity, int list, const int32_t* types) {
   Orc& o = O(c);
   if (list < 0 || list >= (int)o.lists.size() || o.lists[list].arity != arity) FAIL(CHEM_EINVAL, "topology_register");
   o.lists[list].registered.emplace_back(types, types + arity); return 0;
+}
+
+int orc_set_option(void* c, const char* name, double value) {
+  Orc& o = O(c); std::string k = name ? name : "";
+  if (k == "rebuild_criterion") { o.criterion = value != 0 ? 1 : 0; o.resort = true; return 0; }
+  return 0;   // device tuning knobs have no meaning for the scalar restatement
 }
 
 int orc_reactions_enable(void* c, int on) { O(c).react_on = on != 0; return 0; }

@@ -15,6 +15,9 @@ TOL = {64: 1e-10, 32: 2e-4}
 
 
 def both(make_gpu, make_oracle, spec, prec, **kw):
+    # the rebuild trigger is part of the spec so that both sides use the same one
+    # (0: reference's accumulated per-step maxima, 1: max true displacement since the last build)
+    spec.setdefault("rebuild_criterion", 1)
     g, o = make_gpu(prec), make_oracle()
     hg = W.apply(spec, g, **kw)
     ho = W.apply(spec, o, **kw)
@@ -137,11 +140,13 @@ def test_dihedral_and_fene_and_cosine(make_gpu, make_oracle):
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
 
 
-def test_nve_trajectory_matches_oracle_fp64(make_gpu, make_oracle):
+@pytest.mark.parametrize("criterion", [0, 1])
+def test_nve_trajectory_matches_oracle_fp64(make_gpu, make_oracle, criterion):
     spec = W.lj_melt(n=4000, seed=1)
+    spec["rebuild_criterion"] = criterion
     g, o, _ = both(make_gpu, make_oracle, spec, 64, thermostat=False)
     g.run(100); o.run(100)
-    assert g.timers()["rebuilds"] == o.timers()["rebuilds"] >= 4
+    assert g.timers()["rebuilds"] == o.timers()["rebuilds"] >= (4 if criterion == 0 else 3)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
     assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < 1e-8
     assert np.array_equal(g.get_state("IMAGE"), o.get_state("IMAGE"))
@@ -149,6 +154,7 @@ def test_nve_trajectory_matches_oracle_fp64(make_gpu, make_oracle):
 
 def test_fused_and_split_integrator_agree(make_gpu):
     spec = W.lj_melt(n=2048, seed=4, gamma=1.0)
+    spec["rebuild_criterion"] = 0
     a, b = make_gpu(64), make_gpu(64)
     W.apply(spec, a); W.apply(spec, b)
     b.set_option("fuse_integrate", 0)

@@ -50,6 +50,22 @@ def test_nve_energy_and_momentum_conservation(make_oracle):
     assert e.timers()["rebuilds"] >= 10             # skin/2 trigger fired
 
 
+def test_displacement_criterion_rebuilds_less_and_keeps_the_list_valid(make_oracle):
+    """criterion 1 (max |x - x(last build)| > skin/2) is the tighter safe trigger: fewer rebuilds than the
+    reference's accumulated per-step maxima, same physics (the list always covers r < rc)."""
+    outs = []
+    for crit in (0, 1):
+        spec = W.lj_melt(n=864, seed=5)
+        spec["rebuild_criterion"] = crit
+        e = make_oracle()
+        W.apply(spec, e, thermostat=False)
+        e.run(300)
+        outs.append((e.timers()["rebuilds"], e.get_state("POS_UNFOLDED"), e.observe()))
+    assert outs[1][0] < outs[0][0]
+    assert np.allclose(outs[0][1], outs[1][1], atol=1e-6)      # same trajectory up to summation order
+    assert outs[0][2]["epot_lj"] == pytest.approx(outs[1][2]["epot_lj"], rel=1e-9)
+
+
 def test_run_is_split_invariant_without_thermostat(make_oracle):
     """run(a); run(b) == run(a+b): forces are recomputed at every run() start from the same state."""
     spec = W.lj_melt(n=500, seed=2)
