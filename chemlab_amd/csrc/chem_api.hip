@@ -13,6 +13,7 @@
 #include <memory>
 #include <tuple>
 
+#include "chem_comm.hpp"
 #include "chem_host.hpp"
 #include "md_kernels.hpp"
 
@@ -87,6 +88,9 @@ struct Ctx {
   int opt_criterion = 0;     // 1: rebuild when max |x - x(last build)| > skin/2 ; 0: reference's accumulated per-step maxima
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
+  // slab domain decomposition (chem_comm_init)
+  bool dd_on = false; int P = 1, rk = 0;
+  std::unique_ptr<Transport> tr;
   chem_timers tm{};
   virtual ~Ctx() {}
   virtual void run(int64_t nsteps) = 0;
@@ -119,6 +123,17 @@ template <typename R> struct CtxT : Ctx {
   DBuf<TileLDS<R>> tdesc;
   DBuf<long long> dbgbuf; bool dbg_on = false;
   Candidate* pin_ev = nullptr; size_t pin_ev_cap = 0;   // pinned host staging for reaction events
+  // ---- slab decomposition state: reals live at [G, G+n), lower ghosts right-aligned in front of
+  // them, upper ghosts behind; cap = allocated particles
+  int nglob = 0, lower = 0, upper = 0, nzg = 0, z0 = 0, ncz = 0;
+  int G = 0, nglo = 0, ngup = 0, cap = 0, mcap = 0;
+  DBuf<unsigned char> mig[4];          // send down, send up, recv from upper, recv from lower
+  DBuf<int> lcnt_dn, lcnt_up, gcnt_lo, gcnt_up;
+  int halo_dn_off = 0, halo_dn_cnt = 0, halo_up_off = 0, halo_up_cnt = 0;   // slices of the own boundary layers
+  DBuf<double> redbuf;                 // small device buffer for cross-rank reductions
+  DBuf<Candidate> cand_loc; DBuf<int> cnt_all;   // reaction candidates before the all-gather
+  int acap() const { return dd_on ? cap : n; }
+  int64_t dd_rebuilds = 0;
   int S = 0;
   bool use_tiles = false, want32 = false;   // int32 list only built on demand (reaction steps, diagnostics)
   ActMask act{}; UniLJ uni{}; bool uniform_lj = false;
@@ -159,6 +174,20 @@ template <typename R> struct CtxT : Ctx {
       boxd.L[d] = L[d]; boxd.invL[d] = 1.0 / L[d];
     }
     box.ncell = cells ? nc[0] * nc[1] * nc[2] : 1;
+    box.zghost = 0; box.z0g = 0; box.nzg = cells ? nc[2] : 1; box.shz_lo = 0; box.shz_hi = 0;
+    if (dd_on) {
+      if (!cells) throw ChemError(CHEM_EINVAL, "domain decomposition needs at least 3 cells of edge rc+skin per axis");
+      nzg = nc[2];
+      const int base = nzg / P, rem = nzg % P;
+      if (base < 2) throw ChemError(CHEM_EINVAL, "domain decomposition: fewer than 2 cell layers per rank along z");
+      ncz = base + (rk < rem ? 1 : 0);
+      z0 = rk * base + std::min(rk, rem);
+      lower = (rk + P - 1) % P; upper = (rk + 1) % P;
+      box.zghost = 1; box.z0g = z0; box.nzg = nzg; box.nc[2] = ncz + 2;
+      box.ncell = nc[0] * nc[1] * (ncz + 2);
+      box.shz_lo = (R)(z0 == 0 ? -L[2] : 0.0);
+      box.shz_hi = (R)(z0 + ncz == nzg ? L[2] : 0.0);
+    }
   }
 
   // cells, neighbour-list capacity and everything else that depends on box/cutoff/skin
@@ -167,21 +196,22 @@ template <typename R> struct CtxT : Ctx {
     cell_cnt.alloc(box.ncell + 1); cell_start.alloc(box.ncell + 1);
     HIPCHK(hipMemsetAsync(cell_cnt.p, 0, sizeof(int) * (box.ncell + 1), stream));
     const double vol = L[0] * L[1] * L[2], rl = rc + skin;
-    const double expect = 4.0 / 3.0 * M_PI * rl * rl * rl * n / vol;
-    int cap = nl_capacity_user > 0 ? nl_capacity_user : (int)(expect * 1.6 + 48);
-    cap = std::min(cap, std::max(n - 1, 1));
-    S = (cap + 15) / 16 * 16;
-    use_tiles = opt_tiles && box.nc[0] >= HX + 2 && box.nc[1] >= HY + 2 && box.nc[2] >= HZ + 2;
+    const double expect = 4.0 / 3.0 * M_PI * rl * rl * rl * (dd_on ? nglob : n) / vol;
+    int ncap = nl_capacity_user > 0 ? nl_capacity_user : (int)(expect * 1.6 + 48);
+    ncap = std::min(ncap, std::max((dd_on ? nglob : n) - 1, 1));
+    S = (ncap + 15) / 16 * 16;
+    use_tiles = opt_tiles && box.nc[0] >= HX + 2 && box.nc[1] >= HY + 2 && (dd_on ? true : box.nc[2] >= HZ + 2);
+    if (dd_on && !(box.nc[0] >= HX + 2 && box.nc[1] >= HY + 2)) throw ChemError(CHEM_EINVAL, "domain decomposition needs >= 5 cells along x and y");
     if (use_tiles) {
       // LDS capacity from the mean stencil occupancy (+12 % for density fluctuations), in 256-slot steps
-      const double per_cell = (double)n / box.ncell;
+      const double per_cell = dd_on ? (double)nglob / ((double)box.nc[0] * box.nc[1] * nzg) : (double)n / box.ncell;
       const int need = (int)(SX * SY * SZ * per_cell * 1.12) + 64;
       tile_cap = std::max(1024, (need + 255) / 256 * 256);
       const size_t max_lds = 150 * 1024;
       if (tile_lds_bytes() > max_lds) use_tiles = false;   // cells too crowded: per-cell kernels
       else set_tile_lds_attr();
     }
-    ntiles = use_tiles ? ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY) * ((box.nc[2] + HZ - 1) / HZ) : 0;
+    ntiles = use_tiles ? ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY) * (((dd_on ? ncz : box.nc[2]) + HZ - 1) / HZ) : 0;
     alloc_lists();
     HIPCHK(hipStreamSynchronize(stream));
     geom_dirty = false; resort = true;
@@ -201,43 +231,93 @@ template <typename R> struct CtxT : Ctx {
 
   void alloc_lists() {
     nlist.free(); nl16.free();
-    nlist.alloc((size_t)n * S);
-    nnh.alloc(n);
-    if (use_tiles) { nl16.alloc((size_t)n * S); HIPCHK(hipMemsetAsync(nl16.p, 0, (size_t)n * S * 2, stream)); tdesc.alloc(ntiles); }
+    const size_t ac = (size_t)acap();
+    nlist.alloc(ac * S);
+    nnh.alloc(ac);
+    if (use_tiles) { nl16.alloc(ac * S); HIPCHK(hipMemsetAsync(nl16.p, 0, ac * S * 2, stream)); tdesc.alloc(ntiles); }
     tm.nlist_capacity = S;
   }
 
   void upload_particles() {
-    n = (int)top.n;
-    std::vector<V4> hx(n), hv(n);
-    std::vector<int> ht(n);
-    std::vector<int4> hi(n, make_int4(0, 0, 0, 0));
-    for (int t = 0; t < n; ++t) {
-      hx[t].x = (R)pos0[3 * t]; hx[t].y = (R)pos0[3 * t + 1]; hx[t].z = (R)pos0[3 * t + 2]; hx[t].w = (R)top.type[t];
-      hv[t].x = (R)vel0[3 * t]; hv[t].y = (R)vel0[3 * t + 1]; hv[t].z = (R)vel0[3 * t + 2]; hv[t].w = (R)top.mass[t];
-      ht[t] = t;
+    nglob = (int)top.n;
+    n = nglob; G = 0; nglo = ngup = 0; cap = nglob;
+    std::vector<V4> hx, hv; std::vector<int> ht; std::vector<int4> hi;
+    if (dd_on) {
+      setup_box();   // slab bounds (z0, ncz, nzg)
+      // capacities: ghost layers are one cell layer each; reals fluctuate with the slab occupancy
+      const double per_layer = (double)nglob / nzg;
+      G = (int)(per_layer * 1.5) + 1024;
+      mcap = std::max(4096, (int)(per_layer / 4));
+      cap = 2 * G + (int)(per_layer * ncz * 1.2) + 2 * mcap + 4096;
+      hx.assign(cap, V4{}); hv.assign(cap, V4{}); ht.assign(cap, 0); hi.assign(cap, make_int4(0, 0, 0, 0));
+      int k = G;
+      for (int t = 0; t < nglob; ++t) {
+        double z = pos0[3 * t + 2];
+        const double s = std::floor(z / L[2]);
+        z -= s * L[2]; if (z >= L[2]) z -= L[2];
+        int gz = (int)std::floor(z * nzg / L[2]); gz = std::min(std::max(gz, 0), nzg - 1);
+        if (gz < z0 || gz >= z0 + ncz) continue;
+        if (k >= cap - G) throw ChemError(CHEM_ENOSPC, "domain decomposition: slab holds more particles than the allocated capacity");
+        hx[k].x = (R)pos0[3 * t]; hx[k].y = (R)pos0[3 * t + 1]; hx[k].z = (R)z; hx[k].w = (R)top.type[t];
+        hv[k].x = (R)vel0[3 * t]; hv[k].y = (R)vel0[3 * t + 1]; hv[k].z = (R)vel0[3 * t + 2]; hv[k].w = (R)top.mass[t];
+        ht[k] = t; hi[k] = make_int4(0, 0, (int)s, 0);
+        ++k;
+      }
+      n = k - G;
+    } else {
+      hx.resize(n); hv.resize(n); ht.resize(n); hi.assign(n, make_int4(0, 0, 0, 0));
+      for (int t = 0; t < n; ++t) {
+        hx[t].x = (R)pos0[3 * t]; hx[t].y = (R)pos0[3 * t + 1]; hx[t].z = (R)pos0[3 * t + 2]; hx[t].w = (R)top.type[t];
+        hv[t].x = (R)vel0[3 * t]; hv[t].y = (R)vel0[3 * t + 1]; hv[t].z = (R)vel0[3 * t + 2]; hv[t].w = (R)top.mass[t];
+        ht[t] = t;
+      }
     }
-    x4.upload(hx, stream); v4.upload(hv, stream); tag.upload(ht, stream); rtag.upload(ht, stream); img4.upload(hi, stream);
-    f4.alloc(n); x4o.alloc(n); v4o.alloc(n); tago.alloc(n); img4o.alloc(n); x0.alloc(n);
-    HIPCHK(hipMemcpyAsync(x0.p, x4.p, sizeof(V4) * n, hipMemcpyDeviceToDevice, stream));
-    HIPCHK(hipMemsetAsync(f4.p, 0, sizeof(V4) * n, stream));
-    cell_of.alloc(n); slot_of.alloc(n); perm.alloc(n); nn.alloc(n);
-    HIPCHK(hipMemsetAsync(nn.p, 0, sizeof(int) * n, stream));
+    const int ac = acap();
+    x4.upload(hx, stream); v4.upload(hv, stream); tag.upload(ht, stream); img4.upload(hi, stream);
+    {
+      std::vector<int> hr(nglob, -1);
+      for (int k = 0; k < n; ++k) hr[ht[G + k]] = G + k;
+      rtag.upload(hr, stream);
+    }
+    f4.alloc(ac); x4o.alloc(ac); v4o.alloc(ac); tago.alloc(ac); img4o.alloc(ac); x0.alloc(ac);
+    HIPCHK(hipMemcpyAsync(x0.p, x4.p, sizeof(V4) * ac, hipMemcpyDeviceToDevice, stream));
+    HIPCHK(hipMemsetAsync(f4.p, 0, sizeof(V4) * ac, stream));
+    cell_of.alloc(ac); slot_of.alloc(ac); perm.alloc(ac); nn.alloc(ac);
+    HIPCHK(hipMemsetAsync(nn.p, 0, sizeof(int) * ac, stream));
     ctl.alloc(1);
     HIPCHK(hipMemsetAsync(ctl.p, 0, sizeof(DevCtl), stream));
-    blockmax.alloc(cdiv(n, 256));
-    HIPCHK(hipMemsetAsync(blockmax.p, 0, sizeof(unsigned long long) * cdiv(n, 256), stream));
-    eout.alloc(3 * (size_t)cdiv((long long)n * 64, 256) + 8);
-    ekout.alloc(4 * (size_t)cdiv(n, 256) + 8);
+    blockmax.alloc(cdiv(ac, 256));
+    HIPCHK(hipMemsetAsync(blockmax.p, 0, sizeof(unsigned long long) * cdiv(ac, 256), stream));
+    eout.alloc(3 * (size_t)cdiv((long long)ac * 64, 256) + 8);
+    ekout.alloc(4 * (size_t)cdiv(ac, 256) + 8);
     elist.alloc(CHEM_MAX_LISTS);
-    state.alloc(n); res_id.alloc(n); mol_id.alloc(n);
+    redbuf.alloc(64);
+    state.alloc(nglob); res_id.alloc(nglob); mol_id.alloc(nglob);
+    if (dd_on) {
+      const size_t mb = mig_bytes();
+      for (int k = 0; k < 4; ++k) { mig[k].alloc(mb); HIPCHK(hipMemsetAsync(mig[k].p, 0, mb, stream)); }
+    }
     HIPCHK(hipStreamSynchronize(stream));
     pos0.clear(); pos0.shrink_to_fit(); vel0.clear(); vel0.shrink_to_fit();
     particles_dirty = false; labels_dirty = true; geom_dirty = true; resort = true; device_ready = true;
   }
 
+  // migration buffer layout: [count, pad x3][x4 x mcap][v4 x mcap][img4 x mcap][tag x mcap]
+  size_t mig_bytes() const { return 16 + (size_t)mcap * (2 * sizeof(V4) + sizeof(int4) + sizeof(int)); }
+  MigBuf<R> mig_view(int k) {
+    unsigned char* b = mig[k].p;
+    MigBuf<R> m;
+    m.count = reinterpret_cast<int*>(b);
+    m.x = reinterpret_cast<V4*>(b + 16);
+    m.v = m.x + mcap;
+    m.img = reinterpret_cast<int4*>(m.v + mcap);
+    m.tag = reinterpret_cast<int*>(m.img + mcap);
+    m.cap = mcap;
+    return m;
+  }
+
   void upload_labels() {
-    if (state_mirror_stale) { std::vector<int> hs; state.download(hs, n, stream); top.state.assign(hs.begin(), hs.end()); state_mirror_stale = false; }
+    if (state_mirror_stale) { std::vector<int> hs; state.download(hs, nglob, stream); top.state.assign(hs.begin(), hs.end()); state_mirror_stale = false; }
     state.upload(top.state, stream); res_id.upload(top.res_id, stream); mol_id.upload(top.mol_id, stream);
     HIPCHK(hipStreamSynchronize(stream));
     labels_dirty = false;
@@ -331,15 +411,15 @@ template <typename R> struct CtxT : Ctx {
   // ---- rebuild chain (every kernel early-exits unless ctl->need_rebuild) ---------------
   // Grids are capped ("persistent" grid-stride kernels) so that the early-exit launches of the
   // steps that do not rebuild cost ~2 us each instead of a full-size dispatch.
-  void launch_rebuild_chain() {
-    const int nb = std::min(cdiv(n, 256), 2048);
+  void launch_sort_chain(int i0, int npart) {
+    const int nb = std::max(1, std::min(cdiv(npart, 256), 2048));
     DevCtl* c = ctl.p;
-    hipLaunchKernelGGL(k_bin<R>, dim3(nb), dim3(256), 0, stream, n, x4.p, img4.p, box, cell_cnt.p, cell_of.p, slot_of.p, c);
-    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream, box.ncell, cell_cnt.p, cell_start.p, c);
-    hipLaunchKernelGGL(k_place, dim3(nb), dim3(256), 0, stream, n, cell_of.p, slot_of.p, cell_start.p, perm.p, c);
-    hipLaunchKernelGGL(k_sort_gather<R>, dim3(std::min(cdiv(box.ncell, 4), 2048)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p,
-                       x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
-    hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, n, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, x0.p, c);
+    MigBuf<R> mdn{}, mup{};
+    if (dd_on) { mdn = mig_view(0); mup = mig_view(1); }
+    hipLaunchKernelGGL(k_bin<R>, dim3(nb), dim3(256), 0, stream, i0, npart, x4.p, v4.p, tag.p, img4.p, box, cell_cnt.p, cell_of.p, slot_of.p, mdn, mup, c);
+  }
+  void launch_list_chain() {
+    DevCtl* c = ctl.p;
     const R rl2 = (R)((rc + skin) * (rc + skin));
     if (use_tiles) {
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c);
@@ -353,10 +433,90 @@ template <typename R> struct CtxT : Ctx {
       hipLaunchKernelGGL(k_nlist_brute<R>, dim3(cdiv(n, 4)), dim3(256), 0, stream, n, x4.p, tag.p, box, rl2, excl_start.p,
                          excl_list.p, has_excl, nlist.p, nn.p, S, c);
   }
+  void launch_rebuild_chain() {   // single domain
+    const int nb = std::min(cdiv(n, 256), 2048);
+    DevCtl* c = ctl.p;
+    launch_sort_chain(0, n);
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream, box.ncell, 0, cell_cnt.p, cell_start.p, c);
+    hipLaunchKernelGGL(k_place, dim3(nb), dim3(256), 0, stream, 0, n, cell_of.p, slot_of.p, cell_start.p, perm.p, c);
+    hipLaunchKernelGGL(k_sort_gather<R>, dim3(std::min(cdiv(box.ncell, 4), 2048)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p,
+                       x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
+    hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, cell_start.p, 0, box.ncell, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, x0.p, c);
+    launch_list_chain();
+  }
 
   void decide_and_rebuild() {
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin, opt_criterion);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin, opt_criterion, 3);
     launch_rebuild_chain();
+  }
+
+  // ---- slab decomposition ---------------------------------------------------------------
+  int read_int(const int* dev) {
+    int v = 0;
+    HIPCHK(hipMemcpyAsync(&v, dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return v;
+  }
+
+  // Host-synchronous rebuild of one slab: migrate leavers to the z-neighbours, sort the reals,
+  // exchange the boundary layers as ghosts (contiguous slices of the cell-sorted arrays), rebuild
+  // cells/tiles/lists.  Every rank enters together (the trigger is a cross-rank maximum).
+  void rebuild_dd() {
+    const int nxy = box.nc[0] * box.nc[1];
+    set_ctl_field(&DevCtl::need_rebuild, 1);
+    // 1. bin the reals; leavers go to the migration buffers
+    HIPCHK(hipMemsetAsync(mig[0].p, 0, 16, stream)); HIPCHK(hipMemsetAsync(mig[1].p, 0, 16, stream));
+    launch_sort_chain(G, n);
+    // 2. migration exchange (fixed-capacity buffers, count in the header)
+    tr->exchange(mig[0].p, mig_bytes(), mig[1].p, mig_bytes(), mig[2].p, mig_bytes(), mig[3].p, mig_bytes(), lower, upper, stream);
+    const int from_up = read_int(reinterpret_cast<int*>(mig[2].p)), from_lo = read_int(reinterpret_cast<int*>(mig[3].p));
+    if (from_up > mcap || from_lo > mcap) throw ChemError(CHEM_ENOSPC, "domain decomposition: migration buffer overflow");
+    if (G + n + from_lo + from_up > cap - G) throw ChemError(CHEM_ENOSPC, "domain decomposition: slab capacity exceeded by arrivals");
+    // 3. arrivals behind the current reals, then bin them too (they are in their own slab now)
+    if (from_lo) hipLaunchKernelGGL(k_append_arrivals<R>, dim3(cdiv(from_lo, 256)), dim3(256), 0, stream, mig_view(3), from_lo, G + n, x4.p, v4.p, tag.p, img4.p);
+    if (from_up) hipLaunchKernelGGL(k_append_arrivals<R>, dim3(cdiv(from_up, 256)), dim3(256), 0, stream, mig_view(2), from_up, G + n + from_lo, x4.p, v4.p, tag.p, img4.p);
+    const int npend = n + from_lo + from_up;
+    HIPCHK(hipMemsetAsync(mig[0].p, 0, 16, stream)); HIPCHK(hipMemsetAsync(mig[1].p, 0, 16, stream));
+    if (from_lo + from_up) launch_sort_chain(G + n, from_lo + from_up);
+    // 4. sort the reals into [G, G + n_new)
+    DevCtl* c = ctl.p;
+    const int nb = std::max(1, std::min(cdiv(npend, 256), 2048));
+    hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream, box.ncell, G, cell_cnt.p, cell_start.p, c);
+    hipLaunchKernelGGL(k_place, dim3(nb), dim3(256), 0, stream, G, npend, cell_of.p, slot_of.p, cell_start.p, perm.p, c);
+    hipLaunchKernelGGL(k_sort_gather<R>, dim3(std::min(cdiv(box.ncell, 4), 2048)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p,
+                       x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
+    hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nglob, 256)), dim3(256), 0, stream, rtag.p, -1, (size_t)nglob);
+    hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, cell_start.p, nxy, (ncz + 1) * nxy, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, x0.p, c);
+    // 5. boundary-layer counts to the neighbours
+    lcnt_dn.alloc(nxy + 1); lcnt_up.alloc(nxy + 1); gcnt_lo.alloc(nxy + 1); gcnt_up.alloc(nxy + 1);
+    hipLaunchKernelGGL(k_layer_counts, dim3(cdiv(nxy + 1, 256)), dim3(256), 0, stream, nxy, ncz, cell_start.p, lcnt_dn.p, lcnt_up.p);
+    tr->exchange(lcnt_dn.p, (nxy + 1) * sizeof(int), lcnt_up.p, (nxy + 1) * sizeof(int), gcnt_up.p, (nxy + 1) * sizeof(int), gcnt_lo.p,
+                 (nxy + 1) * sizeof(int), lower, upper, stream);
+    n = read_int(cell_start.p + (size_t)(ncz + 1) * nxy) - G;
+    if (read_int(reinterpret_cast<int*>(mig[0].p)) || read_int(reinterpret_cast<int*>(mig[1].p)))
+      throw ChemError(CHEM_ESTATE, "domain decomposition: a migrated particle left its new slab immediately");
+    halo_dn_off = G; halo_dn_cnt = read_int(lcnt_dn.p + nxy);
+    halo_up_cnt = read_int(lcnt_up.p + nxy); halo_up_off = G + n - halo_up_cnt;
+    nglo = read_int(gcnt_lo.p + nxy); ngup = read_int(gcnt_up.p + nxy);
+    if (nglo > G || G + n + ngup > cap) throw ChemError(CHEM_ENOSPC, "domain decomposition: ghost layer exceeds the reserved capacity");
+    // 6. ghost particles: contiguous slices, received in place (lower ghosts right-aligned in front of the reals)
+    tr->exchange(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
+                 x4.p + G - nglo, nglo * sizeof(V4), lower, upper, stream);
+    tr->exchange(tag.p + halo_dn_off, halo_dn_cnt * sizeof(int), tag.p + halo_up_off, halo_up_cnt * sizeof(int), tag.p + G + n, ngup * sizeof(int),
+                 tag.p + G - nglo, nglo * sizeof(int), lower, upper, stream);
+    hipLaunchKernelGGL(k_ghost_cells, dim3(1), dim3(1024), 0, stream, nxy, ncz, gcnt_lo.p, gcnt_up.p, cell_start.p);
+    if (nglo) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(nglo, 256)), dim3(256), 0, stream, G - nglo, nglo, tag.p, rtag.p);
+    if (ngup) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(ngup, 256)), dim3(256), 0, stream, G + n, ngup, tag.p, rtag.p);
+    // 7. tiles + lists over the own layers
+    launch_list_chain();
+    set_ctl_field(&DevCtl::need_rebuild, 0);
+    ++dd_rebuilds;
+  }
+
+  // per-step ghost position update: the same contiguous slices, straight into the ghost ranges
+  void halo_update() {
+    tr->exchange(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
+                 x4.p + G - nglo, nglo * sizeof(V4), lower, upper, stream);
   }
 
   DevCtl read_ctl() {
@@ -376,18 +536,30 @@ template <typename R> struct CtxT : Ctx {
   void rebuild_now() {
     const double t0 = now_s();
     for (int attempt = 0; attempt < 6; ++attempt) {
-      set_ctl_field(&DevCtl::force_rebuild, 1);
-      decide_and_rebuild();
+      if (dd_on) { set_ctl_field(&DevCtl::force_rebuild, 0); set_ctl_field(&DevCtl::acc_maxdist, 0.0); rebuild_dd(); }
+      else { set_ctl_field(&DevCtl::force_rebuild, 1); decide_and_rebuild(); }
       DevCtl h = read_ctl();
+      if (dd_on) agree_flags(h);
+      if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
       if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil holds " + std::to_string(h.stage_overflow) + " particles, LDS tile capacity " + std::to_string(use_tiles ? tile_cap : 1536) + " (density fluctuation beyond the 12 % margin)");
       if (!h.nl_overflow) { resort = false; tm.rebuild_wall_s += now_s() - t0; return; }
       int newS = ((int)(h.nl_overflow * 1.25) + 31) / 16 * 16;
       if (nl_capacity_user > 0) throw ChemError(CHEM_ENOSPC, "neighbour capacity " + std::to_string(S) + " too small, need " + std::to_string(h.nl_overflow));
-      S = std::min(newS, std::max((n + 15) / 16 * 16, 16));
+      S = std::min(newS, std::max(((dd_on ? nglob : n) + 15) / 16 * 16, 16));
       alloc_lists();
       set_ctl_field(&DevCtl::nl_overflow, 0);
     }
     throw ChemError(CHEM_ENOSPC, "neighbour list capacity could not be satisfied");
+  }
+
+  // every rank must take the same branch after a collective rebuild: maxima of the flag words
+  void agree_flags(DevCtl& h) {
+    double v[4] = {(double)h.nl_overflow, (double)h.stage_overflow, (double)h.mig_error, (double)h.skin_violation};
+    HIPCHK(hipMemcpyAsync(redbuf.p, v, sizeof(v), hipMemcpyHostToDevice, stream));
+    tr->allreduce_max_f64(redbuf.p, 4, stream);
+    HIPCHK(hipMemcpyAsync(v, redbuf.p, sizeof(v), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    h.nl_overflow = (int)v[0]; h.stage_overflow = (int)v[1]; h.mig_error = (int)v[2]; h.skin_violation = (int)v[3];
   }
 
   // ---- forces -------------------------------------------------------------------------
@@ -429,8 +601,8 @@ template <typename R> struct CtxT : Ctx {
     launch_pair<false>(f4.p, tpp);
     if (timed) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; }
     if (nbent > 0)
-      hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
-                         bpar.p, boxd, elist.p);
+      hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
+                         bpar.p, boxd, elist.p, ctl.p);
   }
 
   LangevinP<R> lang_params(int64_t istep, int phase) const {
@@ -443,20 +615,35 @@ template <typename R> struct CtxT : Ctx {
     const int nb = cdiv(n, 256);
     LangevinP<R> lp = lang_params(istep, phase);
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p, opt_criterion ? x0.p : (const V4*)nullptr);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr);
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p, opt_criterion ? x0.p : (const V4*)nullptr);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr);
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p, v4.p, f4.p, tag.p, (R)dt, lp, blockmax.p, opt_criterion ? x0.p : (const V4*)nullptr);
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr);
   }
 
   void check_flags() {
     DevCtl h = read_ctl();
-    tm.rebuilds = h.rebuild_count;
+    if (dd_on) agree_flags(h);
+    tm.rebuilds = dd_on ? dd_rebuilds : h.rebuild_count;
+    if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
+    if (h.bonded_missing) throw ChemError(CHEM_ESTATE, "domain decomposition: a bonded partner is farther than the ghost layer (rc+skin)");
     if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil exceeded the LDS tile capacity (" + std::to_string(h.stage_overflow) + " particles)");
     if (h.nl_overflow) throw ChemError(CHEM_ENOSPC, "neighbour row overflow during run: needed " + std::to_string(h.nl_overflow) + ", capacity " + std::to_string(S) + " (chem_set_nlist_capacity)");
     if (h.skin_violation) throw ChemError(CHEM_ESTATE, "internal: neighbour list used past skin/2");
     if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
+  }
+
+  // one step's neighbour bookkeeping in slab mode: cross-rank max of the displacement, the ghost
+  // position update (posted before the decision is known: it is needed unless we rebuild), and the
+  // collective rebuild when the trigger fired.  One host synchronisation per step.
+  void dd_step_sync() {
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), 256), 0.5 * skin, opt_criterion, 1);
+    tr->allreduce_max_f64(&ctl.p->step_m2, 1, stream);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, 0, 0.5 * skin, opt_criterion, 2);
+    halo_update();
+    DevCtl h = read_ctl();
+    if (h.need_rebuild) rebuild_dd();
   }
 
   // ---- the hot call -------------------------------------------------------------------
@@ -475,7 +662,7 @@ template <typename R> struct CtxT : Ctx {
     bool need_int1 = true;
     for (int64_t s = 0; s < nsteps; ++s) {
       if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
-      decide_and_rebuild();
+      if (dd_on) dd_step_sync(); else decide_and_rebuild();
       compute_forces();
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
       const bool last = (s == nsteps - 1);
@@ -514,9 +701,10 @@ template <typename R> struct CtxT : Ctx {
     tm.reaction_steps++;
     if (reactions.empty()) return;
     if (cand_cap == 0) {
-      cand_cap = std::max(8 * n, 1024);
+      cand_cap = std::max(8 * nglob, 1024);
       cand.alloc(cand_cap); evout.alloc(cand_cap); st0.alloc(cand_cap); st1.alloc(cand_cap);
-      asA.alloc(n); asB.alloc(n); best1.alloc(n); best2.alloc(n); evcount.alloc(1); rs_dev.alloc(1);
+      asA.alloc(nglob); asB.alloc(nglob); best1.alloc(nglob); best2.alloc(nglob); evcount.alloc(1); rs_dev.alloc(1);
+      if (dd_on) { cand_loc.alloc((size_t)cand_cap); cnt_all.alloc(64); }
     }
     ReactSet rs{};
     rs.n = (int)reactions.size(); rs.seed = react_seed; rs.step = (uint64_t)step; rs.nearest = nearest;
@@ -532,30 +720,54 @@ template <typename R> struct CtxT : Ctx {
     }
     HIPCHK(hipMemcpyAsync(rs_dev.p, &rs, sizeof(ReactSet), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    Trace tr("react");
+    Trace trc("react");
     ensure_list32();
-    tr.lap("list32");
+    trc.lap("list32");
     set_ctl_field(&DevCtl::cand_count, 0);
-    hipLaunchKernelGGL(k_react_scan<R>, dim3(cdiv((long long)n * 8, 256)), dim3(256), 0, stream, n, x4.p, tag.p, nlist.p, nn.p, S, state.p,
-                       res_id.p, mol_id.p, boxd, rs_dev.p, cand.p, cand_cap, ctl.p);
+    hipLaunchKernelGGL(k_react_scan<R>, dim3(cdiv((long long)n * 8, 256)), dim3(256), 0, stream, G, n, x4.p, tag.p, nlist.p, nn.p, S, state.p,
+                       res_id.p, mol_id.p, boxd, rs_dev.p, dd_on ? cand_loc.p : cand.p, cand_cap, ctl.p);
     DevCtl h = read_ctl();
-    tr.lap("scan");
+    trc.lap("scan");
     if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
-    const int nc = h.cand_count;
+    int nc = h.cand_count;
+    if (dd_on) {
+      // A boundary pair is seen by two ranks (real-ghost on each); the scan emits it only where the
+      // particle with the lower tag is owned, so the union over ranks holds every candidate once.
+      // All ranks then run the same deterministic resolve on the gathered set (one exchange).
+      std::vector<int> cnts(P, 0);
+      HIPCHK(hipMemcpyAsync(cnt_all.p + rk, &nc, sizeof(int), hipMemcpyHostToDevice, stream));
+      tr->allgather(cnt_all.p + rk, cnt_all.p, sizeof(int), stream);
+      HIPCHK(hipMemcpyAsync(cnts.data(), cnt_all.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      int mx = 0, tot = 0;
+      for (int v : cnts) { mx = std::max(mx, v); tot += v; }
+      if ((long long)mx * P > cand_cap || tot > cand_cap) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow (gathered)");
+      if (mx > 0) {
+        // padded all-gather into evout (scratch here), then compaction into cand in rank order
+        HIPCHK(hipMemcpyAsync(evout.p + (size_t)rk * mx, cand_loc.p, sizeof(Candidate) * nc, hipMemcpyDeviceToDevice, stream));
+        tr->allgather(evout.p + (size_t)rk * mx, evout.p, sizeof(Candidate) * mx, stream);
+        int off = 0;
+        for (int r = 0; r < P; ++r) {
+          if (cnts[r]) HIPCHK(hipMemcpyAsync(cand.p + off, evout.p + (size_t)r * mx, sizeof(Candidate) * cnts[r], hipMemcpyDeviceToDevice, stream));
+          off += cnts[r];
+        }
+      }
+      nc = tot;
+    }
     if (nc == 0) { tm.reaction_wall_s += now_s() - t0; return; }
-    const int ncb = cdiv(nc, 256), npb = cdiv(n, 256);
+    const int ncb = cdiv(nc, 256), npb = cdiv(nglob, 256);
     hipLaunchKernelGGL(k_fill<int>, dim3(ncb), dim3(256), 0, stream, st0.p, 1, (size_t)nc);
     for (int side = 0; side < 2; ++side) {
-      hipLaunchKernelGGL(k_fill<unsigned long long>, dim3(npb), dim3(256), 0, stream, best1.p, ~0ull, (size_t)n);
-      hipLaunchKernelGGL(k_fill<unsigned long long>, dim3(npb), dim3(256), 0, stream, best2.p, ~0ull, (size_t)n);
+      hipLaunchKernelGGL(k_fill<unsigned long long>, dim3(npb), dim3(256), 0, stream, best1.p, ~0ull, (size_t)nglob);
+      hipLaunchKernelGGL(k_fill<unsigned long long>, dim3(npb), dim3(256), 0, stream, best2.p, ~0ull, (size_t)nglob);
       hipLaunchKernelGGL(k_res_min1, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, side, nearest, best1.p);
       hipLaunchKernelGGL(k_res_min2, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, side, nearest, best1.p, best2.p);
       hipLaunchKernelGGL(k_res_keep, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, side, nearest, best1.p, best2.p);
     }
-    hipLaunchKernelGGL(k_fill<int>, dim3(npb), dim3(256), 0, stream, asA.p, -1, (size_t)n);
-    hipLaunchKernelGGL(k_fill<int>, dim3(npb), dim3(256), 0, stream, asB.p, -1, (size_t)n);
+    hipLaunchKernelGGL(k_fill<int>, dim3(npb), dim3(256), 0, stream, asA.p, -1, (size_t)nglob);
+    hipLaunchKernelGGL(k_fill<int>, dim3(npb), dim3(256), 0, stream, asB.p, -1, (size_t)nglob);
     hipLaunchKernelGGL(k_res_index, dim3(ncb), dim3(256), 0, stream, nc, cand.p, st0.p, asA.p, asB.p);
-    if (g_trace) { HIPCHK(hipStreamSynchronize(stream)); tr.lap("uniqueAB"); }
+    if (g_trace) { HIPCHK(hipStreamSynchronize(stream)); trc.lap("uniqueAB"); }
     int* sin = st0.p; int* sout = st1.p;
     for (int batch = 0; batch < 20000; ++batch) {
       // `alive` is only meaningful for the last round of a batch: extra rounds on a finished
@@ -567,7 +779,7 @@ template <typename R> struct CtxT : Ctx {
       }
       if (read_ctl().alive == 0) break;
     }
-    if (g_trace) { fprintf(stderr, "[chem trace] candidates %d\n", nc); tr.lap("rounds"); }
+    if (g_trace) { fprintf(stderr, "[chem trace] candidates %d\n", nc); trc.lap("rounds"); }
     HIPCHK(hipMemsetAsync(evcount.p, 0, sizeof(int), stream));
     hipLaunchKernelGGL(k_react_apply<R>, dim3(ncb), dim3(256), 0, stream, nc, cand.p, sin, ras, state.p, rtag.p, x4.p, v4.p, evout.p, evcount.p);
     int nev = 0;
@@ -581,7 +793,7 @@ template <typename R> struct CtxT : Ctx {
     if (nev) HIPCHK(hipMemcpyAsync(pin_ev, evout.p, (size_t)nev * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     std::vector<Candidate> hev(pin_ev, pin_ev + nev);
-    tr.lap("resolve+apply+download");
+    trc.lap("resolve+apply+download");
     // Host mirrors + topology.  Only bond-forming events need the canonical order now (it fixes
     // the order of the bond lists); the event log itself is put in canonical order lazily
     // by chem_get_events.
@@ -610,13 +822,13 @@ template <typename R> struct CtxT : Ctx {
       }
     }
     state_mirror_stale = true;
-    tr.lap("host events");
+    trc.lap("host events");
     if (!newbonds.empty()) {
       std::vector<int32_t> touched;
       top.on_new_bonds(newbonds, touched);
-      tr.lap("on_new_bonds");
+      trc.lap("on_new_bonds");
       res_id.upload(top.res_id, stream); mol_id.upload(top.mol_id, stream);
-      upload_bonded(); tr.lap("upload_bonded"); upload_excl(); tr.lap("upload_excl");
+      upload_bonded(); trc.lap("upload_bonded"); upload_excl(); trc.lap("upload_excl");
       resort = true;
       set_ctl_field(&DevCtl::force_rebuild, 1);
     }
@@ -630,47 +842,80 @@ template <typename R> struct CtxT : Ctx {
   }
 
   // ---- read-back ------------------------------------------------------------------------
+  // ---- cross-rank gather of fixed-size host records (read-back paths only) ---------------
+  DBuf<unsigned char> gbuf;
+  std::vector<unsigned char> gather_records(const std::vector<unsigned char>& loc, size_t rec) {
+    if (!dd_on || P == 1) return loc;
+    if (!cnt_all.p) cnt_all.alloc(64);
+    int nloc = (int)(loc.size() / rec);
+    std::vector<int> cnts(P, 0);
+    HIPCHK(hipMemcpyAsync(cnt_all.p + rk, &nloc, sizeof(int), hipMemcpyHostToDevice, stream));
+    tr->allgather(cnt_all.p + rk, cnt_all.p, sizeof(int), stream);
+    HIPCHK(hipMemcpyAsync(cnts.data(), cnt_all.p, sizeof(int) * P, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    size_t mx = 0, tot = 0;
+    for (int v : cnts) { mx = std::max<size_t>(mx, v); tot += v; }
+    std::vector<unsigned char> all(tot * rec);
+    if (mx == 0) return all;
+    gbuf.alloc(mx * rec * P);
+    if (nloc) HIPCHK(hipMemcpyAsync(gbuf.p + (size_t)rk * mx * rec, loc.data(), loc.size(), hipMemcpyHostToDevice, stream));
+    tr->allgather(gbuf.p + (size_t)rk * mx * rec, gbuf.p, mx * rec, stream);
+    std::vector<unsigned char> raw(mx * rec * P);
+    HIPCHK(hipMemcpyAsync(raw.data(), gbuf.p, raw.size(), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    size_t off = 0;
+    for (int r = 0; r < P; ++r) { std::memcpy(all.data() + off, raw.data() + (size_t)r * mx * rec, (size_t)cnts[r] * rec); off += (size_t)cnts[r] * rec; }
+    return all;
+  }
+
+  struct StateRec { int tag, pad; double v[3]; };
+
+  // ---- read-back ------------------------------------------------------------------------
   int64_t get_state(int what, void* out, int64_t cap) override {
     flush_host_state();
     const int per = (what == CHEM_STATE_POS || what == CHEM_STATE_VEL || what == CHEM_STATE_FORCE || what == CHEM_STATE_IMAGE || what == CHEM_STATE_POS_UNFOLDED) ? 3 : 1;
-    if (cap < (int64_t)n * per) throw ChemError(CHEM_ENOSPC, "get_state: capacity");
-    std::vector<int> ht; tag.download(ht, n, stream);
+    if (cap < (int64_t)nglob * per) throw ChemError(CHEM_ENOSPC, "get_state: capacity");
     double* d = (double*)out; int32_t* i32 = (int32_t*)out; int64_t* i64 = (int64_t*)out;
-    auto vec3 = [&](DBuf<V4>& src, bool want_w) {
-      std::vector<V4> h; src.download(h, n, stream);
-      for (int i = 0; i < n; ++i) {
-        const int t = ht[i];
-        if (want_w) d[t] = (double)h[i].w;
-        else { d[3 * t] = (double)h[i].x; d[3 * t + 1] = (double)h[i].y; d[3 * t + 2] = (double)h[i].z; }
-      }
-    };
-    switch (what) {
-      case CHEM_STATE_POS: case CHEM_STATE_POS_UNFOLDED: {
-        std::vector<V4> h; x4.download(h, n, stream);
-        std::vector<int4> hi; img4.download(hi, n, stream);
-        for (int i = 0; i < n; ++i) {
-          const int t = ht[i];
-          double p[3] = {(double)h[i].x, (double)h[i].y, (double)h[i].z};
-          const int im[3] = {hi[i].x, hi[i].y, hi[i].z};
-          for (int k = 0; k < 3; ++k) {
-            if (what == CHEM_STATE_POS) { double s = std::floor(p[k] / L[k]); p[k] -= s * L[k]; if (p[k] >= L[k]) p[k] -= L[k]; }
-            else p[k] += im[k] * L[k];
-            d[3 * t + k] = p[k];
-          }
-        }
-        break; }
-      case CHEM_STATE_VEL: vec3(v4, false); break;
-      case CHEM_STATE_FORCE: vec3(f4, false); break;
-      case CHEM_STATE_MASS: vec3(v4, true); break;
-      case CHEM_STATE_TYPE: { std::vector<V4> h; x4.download(h, n, stream); for (int i = 0; i < n; ++i) i32[ht[i]] = (int32_t)h[i].w; break; }
-      case CHEM_STATE_STATE: { std::vector<int> h; state.download(h, n, stream); std::copy(h.begin(), h.end(), i32); break; }
-      case CHEM_STATE_RESID: { std::vector<int> h; res_id.download(h, n, stream); std::copy(h.begin(), h.end(), i32); break; }
-      case CHEM_STATE_MOLID: { std::vector<int> h; mol_id.download(h, n, stream); for (int t = 0; t < n; ++t) i32[t] = (int32_t)top.id[h[t]]; break; }
-      case CHEM_STATE_ID: for (int t = 0; t < n; ++t) i64[t] = top.id[t]; break;
-      case CHEM_STATE_IMAGE: { std::vector<int4> hi; img4.download(hi, n, stream); for (int i = 0; i < n; ++i) { const int t = ht[i]; i32[3 * t] = hi[i].x; i32[3 * t + 1] = hi[i].y; i32[3 * t + 2] = hi[i].z; } break; }
-      default: throw ChemError(CHEM_EINVAL, "get_state: unknown selector");
+    switch (what) {   // replicated by-tag data: no gather
+      case CHEM_STATE_STATE: { std::vector<int> h; state.download(h, nglob, stream); std::copy(h.begin(), h.end(), i32); return nglob; }
+      case CHEM_STATE_RESID: { std::vector<int> h; res_id.download(h, nglob, stream); std::copy(h.begin(), h.end(), i32); return nglob; }
+      case CHEM_STATE_MOLID: { std::vector<int> h; mol_id.download(h, nglob, stream); for (int t = 0; t < nglob; ++t) i32[t] = (int32_t)top.id[h[t]]; return nglob; }
+      case CHEM_STATE_ID: for (int t = 0; t < nglob; ++t) i64[t] = top.id[t]; return nglob;
+      default: break;
     }
-    return n;
+    // per-particle data of the owned range [G, G+n)
+    std::vector<int> ht(n); std::vector<V4> hv(n); std::vector<int4> hi;
+    if (n) HIPCHK(hipMemcpyAsync(ht.data(), tag.p + G, sizeof(int) * n, hipMemcpyDeviceToHost, stream));
+    const V4* src = (what == CHEM_STATE_VEL || what == CHEM_STATE_MASS) ? v4.p : (what == CHEM_STATE_FORCE ? f4.p : x4.p);
+    if (n) HIPCHK(hipMemcpyAsync(hv.data(), src + G, sizeof(V4) * n, hipMemcpyDeviceToHost, stream));
+    if (what == CHEM_STATE_POS_UNFOLDED || what == CHEM_STATE_IMAGE) { hi.resize(n); if (n) HIPCHK(hipMemcpyAsync(hi.data(), img4.p + G, sizeof(int4) * n, hipMemcpyDeviceToHost, stream)); }
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<unsigned char> loc((size_t)n * sizeof(StateRec));
+    StateRec* rec = reinterpret_cast<StateRec*>(loc.data());
+    for (int i = 0; i < n; ++i) {
+      StateRec r{ht[i], 0, {(double)hv[i].x, (double)hv[i].y, (double)hv[i].z}};
+      if (what == CHEM_STATE_POS) { for (int k = 0; k < 3; ++k) { double s = std::floor(r.v[k] / L[k]); r.v[k] -= s * L[k]; if (r.v[k] >= L[k]) r.v[k] -= L[k]; } }
+      else if (what == CHEM_STATE_POS_UNFOLDED) { r.v[0] += hi[i].x * L[0]; r.v[1] += hi[i].y * L[1]; r.v[2] += hi[i].z * L[2]; }
+      else if (what == CHEM_STATE_IMAGE) { r.v[0] = hi[i].x; r.v[1] = hi[i].y; r.v[2] = hi[i].z; }
+      else if (what == CHEM_STATE_MASS || what == CHEM_STATE_TYPE) r.v[0] = (double)hv[i].w;
+      rec[i] = r;
+    }
+    const std::vector<unsigned char> all = gather_records(loc, sizeof(StateRec));
+    const StateRec* ar = reinterpret_cast<const StateRec*>(all.data());
+    const size_t na = all.size() / sizeof(StateRec);
+    if ((int64_t)na != nglob) throw ChemError(CHEM_ESTATE, "get_state: owned particles do not add up to the global count (" + std::to_string(na) + " vs " + std::to_string(nglob) + ")");
+    for (size_t k = 0; k < na; ++k) {
+      const int t = ar[k].tag;
+      switch (what) {
+        case CHEM_STATE_MASS: d[t] = ar[k].v[0]; break;
+        case CHEM_STATE_TYPE: i32[t] = (int32_t)ar[k].v[0]; break;
+        case CHEM_STATE_IMAGE: for (int c = 0; c < 3; ++c) i32[3 * t + c] = (int32_t)ar[k].v[c]; break;
+        default: for (int c = 0; c < 3; ++c) d[3 * t + c] = ar[k].v[c]; break;
+      }
+    }
+    if (what != CHEM_STATE_POS && what != CHEM_STATE_POS_UNFOLDED && what != CHEM_STATE_VEL && what != CHEM_STATE_FORCE && what != CHEM_STATE_MASS &&
+        what != CHEM_STATE_TYPE && what != CHEM_STATE_IMAGE) throw ChemError(CHEM_EINVAL, "get_state: unknown selector");
+    return nglob;
   }
 
   void observe(chem_obs* out) override {
@@ -681,32 +926,46 @@ template <typename R> struct CtxT : Ctx {
     const int nb = launch_pair<true>(x4o.p, tpp);  // scratch force buffer: leaves f4 untouched
     HIPCHK(hipMemsetAsync(elist.p, 0, sizeof(double) * CHEM_MAX_LISTS, stream));
     if (nbent > 0)
-      hipLaunchKernelGGL((k_bonded<R, true>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n, x4.p, x4o.p, tag.p, rtag.p, bstart.p, bent.p,
-                         bpar.p, boxd, elist.p);
+      hipLaunchKernelGGL((k_bonded<R, true>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, x4o.p, tag.p, rtag.p, bstart.p, bent.p,
+                         bpar.p, boxd, elist.p, ctl.p);
     const int nkb = cdiv(n, 256);
-    hipLaunchKernelGGL(k_kinetic<R>, dim3(nkb), dim3(256), 0, stream, n, v4.p, ekout.p);
+    hipLaunchKernelGGL(k_kinetic<R>, dim3(nkb), dim3(256), 0, stream, G, n, v4.p, ekout.p);
     std::vector<double> he, hk, hl;
     eout.download(he, 3 * (size_t)nb, stream); ekout.download(hk, 4 * (size_t)nkb, stream); elist.download(hl, CHEM_MAX_LISTS, stream);
-    double elj = 0, etab = 0, vir = 0, ek = 0, p[3] = {0, 0, 0};
-    for (int b = 0; b < nb; ++b) { elj += he[3 * b]; etab += he[3 * b + 1]; vir += he[3 * b + 2]; }
-    for (int b = 0; b < nkb; ++b) { ek += hk[4 * b]; p[0] += hk[4 * b + 1]; p[1] += hk[4 * b + 2]; p[2] += hk[4 * b + 3]; }
-    out->step = step; out->npart = n; out->ekin = ek; out->temperature = 2.0 * ek / (3.0 * n);
-    out->epot_lj = elj; out->epot_tab = etab; out->virial_nb = vir;
-    for (int k = 0; k < 3; ++k) out->momentum[k] = p[k];
-    for (size_t l = 0; l < top.lists.size(); ++l) { out->epot_list[l] = hl[l]; out->list_size[l] = top.lists[l].size(); }
+    double acc[8 + CHEM_MAX_LISTS] = {0};   // elj, etab, vir, ek, px, py, pz, -, lists...
+    for (int b = 0; b < nb; ++b) { acc[0] += he[3 * b]; acc[1] += he[3 * b + 1]; acc[2] += he[3 * b + 2]; }
+    for (int b = 0; b < nkb; ++b) { acc[3] += hk[4 * b]; acc[4] += hk[4 * b + 1]; acc[5] += hk[4 * b + 2]; acc[6] += hk[4 * b + 3]; }
+    for (int l = 0; l < CHEM_MAX_LISTS; ++l) acc[8 + l] = hl[l];
+    if (dd_on && P > 1) {
+      HIPCHK(hipMemcpyAsync(redbuf.p, acc, sizeof(acc), hipMemcpyHostToDevice, stream));
+      tr->allreduce_sum_f64(redbuf.p, 8 + CHEM_MAX_LISTS, stream);
+      HIPCHK(hipMemcpyAsync(acc, redbuf.p, sizeof(acc), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    out->step = step; out->npart = nglob; out->ekin = acc[3]; out->temperature = 2.0 * acc[3] / (3.0 * nglob);
+    out->epot_lj = acc[0]; out->epot_tab = acc[1]; out->virial_nb = acc[2];
+    for (int k = 0; k < 3; ++k) out->momentum[k] = acc[4 + k];
+    for (size_t l = 0; l < top.lists.size(); ++l) { out->epot_list[l] = acc[8 + l]; out->list_size[l] = top.lists[l].size(); }
   }
 
   int64_t verlet_pairs(int64_t* out, int64_t cap) override {
     flush_host_state();
     ensure_list32();
+    const int ac = acap();
     std::vector<int> hn, ht, hl;
-    nn.download(hn, n, stream); tag.download(ht, n, stream); nlist.download(hl, (size_t)n * S, stream);
-    std::vector<std::pair<int64_t, int64_t>> pr;
-    for (int i = 0; i < n; ++i)
+    nn.download(hn, ac, stream); tag.download(ht, ac, stream); nlist.download(hl, (size_t)ac * S, stream);
+    std::vector<unsigned char> loc;
+    for (int i = G; i < G + n; ++i)
       for (int k = 0; k < hn[i]; ++k) {
         const int a = ht[i], b = ht[hl[(size_t)i * S + k]];
-        pr.emplace_back(top.id[std::min(a, b)], top.id[std::max(a, b)]);
+        const int pr2[2] = {std::min(a, b), std::max(a, b)};
+        const unsigned char* pb = reinterpret_cast<const unsigned char*>(pr2);
+        loc.insert(loc.end(), pb, pb + 8);
       }
+    const std::vector<unsigned char> all = gather_records(loc, 8);
+    std::vector<std::pair<int64_t, int64_t>> pr;
+    pr.reserve(all.size() / 8);
+    for (size_t k = 0; k + 8 <= all.size(); k += 8) { int ab[2]; std::memcpy(ab, all.data() + k, 8); pr.emplace_back(top.id[ab[0]], top.id[ab[1]]); }
     std::sort(pr.begin(), pr.end());
     pr.erase(std::unique(pr.begin(), pr.end()), pr.end());
     const int64_t m = (int64_t)pr.size();
@@ -728,8 +987,9 @@ template <typename R> struct CtxT : Ctx {
 
   void refresh_timers() override {
     if (!device_ready || particles_dirty) return;
-    std::vector<int> hn; (use_tiles ? nnh : nn).download(hn, n, stream);
-    long long tot = 0; for (int v : hn) tot += v;
+    std::vector<int> hn; (use_tiles ? nnh : nn).download(hn, acap(), stream);
+    long long tot = 0;
+    if (use_tiles) { for (int k = 0; k < n; ++k) tot += hn[k]; } else { for (int k = G; k < G + n; ++k) tot += hn[k]; }
     tm.nlist_entries = tot; tm.nlist_capacity = S;
   }
 
@@ -1086,6 +1346,16 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "ablate") CTX.opt_ablate = (int)value;
   else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; }
   else if (k == "debug_stamps") CTX.debug_enable((int)value);
+  else if (k == "dd_self") {   // testing: one rank, ghost layers in z exchanged with itself by device copies
+    REQUIRE(CTX.particles_dirty && !CTX.dd_on, CHEM_ESTATE, "dd_self must be set before the first run");
+    if (value != 0) { CTX.tr.reset(new SelfTransport()); CTX.dd_on = true; CTX.P = 1; CTX.rk = 0; CTX.geom_dirty = true; }
+  }
+  else if (k == "dd_self_rccl") {   // testing: the same through RCCL (one-rank communicator, send/recv to self)
+    REQUIRE(CTX.particles_dirty && !CTX.dd_on, CHEM_ESTATE, "dd_self_rccl must be set before the first run");
+    char uid[128];
+    REQUIRE(chem_comm_unique_id(uid) == 0, CHEM_ECOMM, "cannot create an RCCL unique id");
+    CTX.tr.reset(new RcclTransport(1, 0, uid)); CTX.dd_on = true; CTX.P = 1; CTX.rk = 0; CTX.geom_dirty = true;
+  }
   else if (k == "skip_inactive_pairs") { CTX.opt_skip_inactive = value != 0; CTX.pair_dirty = true; }
   else throw ChemError(CHEM_EINVAL, "unknown option " + k);
   return 0;
@@ -1095,12 +1365,28 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
 // diagnostic: per-tile phase stamps of the last pair-force launch (6 int64 per tile); not part of the public header
 int64_t chem_debug_dump(chem_ctx* ctx, long long* out, int64_t cap) { return ctx->c->debug_dump(out, cap); }
 
-int chem_comm_unique_id(char uid[128]) { (void)uid; return CHEM_ENOTIMPL; }
+int chem_comm_unique_id(char uid[128]) {
+  RcclApi& a = rccl_api();
+  if (!a.load()) { g_create_error = a.err; return CHEM_ECOMM; }
+  RcclApi::UniqueId id;
+  if (a.GetUniqueId(&id) != 0) { g_create_error = "ncclGetUniqueId failed"; return CHEM_ECOMM; }
+  std::memcpy(uid, id.internal, 128);
+  return 0;
+}
+
 int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], const char uid[128]) {
   API_BEGIN
-  (void)rank; (void)node_grid; (void)uid;
-  if (nranks == 1) return 0;
-  throw ChemError(CHEM_ENOTIMPL, "multi-GPU domain decomposition is not built yet");
+  Ctx& c = CTX;
+  REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, CHEM_EINVAL, "comm_init: rank/nranks");
+  REQUIRE(!c.dd_on, CHEM_ESTATE, "comm_init: already initialised");
+  if (nranks == 1 && !uid) return 0;   // single domain, nothing to do
+  REQUIRE(node_grid && node_grid[0] == 1 && node_grid[1] == 1 && node_grid[2] == nranks, CHEM_ENOTIMPL,
+          "comm_init: this build decomposes along z only, node grid must be (1,1,nranks)");
+  REQUIRE(uid, CHEM_EINVAL, "comm_init: unique id");
+  REQUIRE(c.particles_dirty, CHEM_ESTATE, "comm_init must precede the first run (particles are already on the device)");
+  c.tr.reset(new RcclTransport(nranks, rank, uid));
+  c.dd_on = true; c.P = nranks; c.rk = rank; c.geom_dirty = true;
+  return 0;
   API_END(ctx)
 }
 

@@ -1,0 +1,124 @@
+// chem_comm.hpp -- neighbour transport of the slab domain decomposition.
+//
+// The reference reaches MPI through boost::mpi inside ESPResSo++ (storage.DomainDecomposition,
+// src/start_simulation.py:152-163); here one process drives one GPU and the ghost layers travel as
+// contiguous device slices over RCCL point-to-point (xGMI).  RCCL is opened with dlopen at
+// chem_comm_init time, so single-GPU use has no RCCL dependency.
+//
+//   RcclTransport : production, one rank per GPU.
+//   SelfTransport : one rank whose lower and upper z-neighbour are itself (device-to-device copies);
+//                   exercises the whole ghost/migration machinery on a single GPU.
+#pragma once
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "chem_host.hpp"
+
+namespace chem {
+
+struct Transport {
+  int nranks = 1, rank = 0;
+  virtual ~Transport() {}
+  // One exchange phase with the z-neighbours: `dn` goes to the lower neighbour, `up` to the upper
+  // one; `from_up` receives what the upper neighbour sent down, `from_lo` what the lower sent up.
+  // Byte counts; all four may differ.  Enqueued on `s`.
+  virtual void exchange(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
+                        void* from_lo, size_t from_lo_bytes, int lower, int upper, hipStream_t s) = 0;
+  virtual void allreduce_max_f64(double* dev, size_t count, hipStream_t s) = 0;
+  virtual void allreduce_sum_f64(double* dev, size_t count, hipStream_t s) = 0;
+  // out must hold nranks*bytes; in may alias out + rank*bytes
+  virtual void allgather(const void* in, void* out, size_t bytes, hipStream_t s) = 0;
+};
+
+struct SelfTransport : Transport {
+  void exchange(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes, void* from_lo,
+                size_t from_lo_bytes, int, int, hipStream_t s) override {
+    // my own "down" message arrives from my upper neighbour (= me) and vice versa
+    if (dn_bytes != from_up_bytes || up_bytes != from_lo_bytes) throw ChemError(CHEM_ECOMM, "self transport: size mismatch");
+    if (dn_bytes && hipMemcpyAsync(from_up, dn, dn_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) throw ChemError(CHEM_ECOMM, "self copy");
+    if (up_bytes && hipMemcpyAsync(from_lo, up, up_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) throw ChemError(CHEM_ECOMM, "self copy");
+  }
+  void allreduce_max_f64(double*, size_t, hipStream_t) override {}
+  void allreduce_sum_f64(double*, size_t, hipStream_t) override {}
+  void allgather(const void* in, void* out, size_t bytes, hipStream_t s) override {
+    if (in != out && bytes) (void)hipMemcpyAsync(out, in, bytes, hipMemcpyDeviceToDevice, s);
+  }
+};
+
+// ---- RCCL through dlopen ---------------------------------------------------------------
+struct RcclApi {
+  typedef struct { char internal[128]; } UniqueId;
+  typedef void* Comm;
+  // enums mirror rccl.h
+  enum { kInt8 = 0, kFloat64 = 8 };
+  enum { kSum = 0, kMax = 2 };
+  int (*GetUniqueId)(UniqueId*) = nullptr;
+  int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
+  int (*CommDestroy)(Comm) = nullptr;
+  int (*Send)(const void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  void* handle = nullptr;
+  std::string err;
+
+  bool load() {
+    if (handle) return true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) { handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (handle) break; }
+    if (!handle) { err = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
+#define SYM(field, name) *(void**)(&field) = dlsym(handle, name); if (!field) { err = std::string("missing RCCL symbol ") + name; return false; }
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+    SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(AllReduce, "ncclAllReduce") SYM(AllGather, "ncclAllGather")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return true;
+  }
+};
+
+inline RcclApi& rccl_api() { static RcclApi a; return a; }
+
+struct RcclTransport : Transport {
+  RcclApi::Comm comm = nullptr;
+  void ck(int rc, const char* what) {
+    if (rc != 0) throw ChemError(CHEM_ECOMM, std::string(what) + ": " + rccl_api().GetErrorString(rc));
+  }
+  RcclTransport(int nr, int rk, const char uid[128]) {
+    nranks = nr; rank = rk;
+    RcclApi& a = rccl_api();
+    if (!a.load()) throw ChemError(CHEM_ECOMM, a.err);
+    RcclApi::UniqueId id; std::memcpy(id.internal, uid, 128);
+    ck(a.CommInitRank(&comm, nr, id, rk), "ncclCommInitRank");
+  }
+  ~RcclTransport() override { if (comm) rccl_api().CommDestroy(comm); }
+  void exchange(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes, void* from_lo,
+                size_t from_lo_bytes, int lower, int upper, hipStream_t s) override {
+    RcclApi& a = rccl_api();
+    // Order matters when lower == upper (two ranks): the k-th send to a peer pairs with its k-th
+    // receive from us.  Everybody sends [down, up] and receives [from upper, from lower].
+    ck(a.GroupStart(), "ncclGroupStart");
+    ck(a.Send(dn, dn_bytes, RcclApi::kInt8, lower, comm, s), "ncclSend");
+    ck(a.Send(up, up_bytes, RcclApi::kInt8, upper, comm, s), "ncclSend");
+    ck(a.Recv(from_up, from_up_bytes, RcclApi::kInt8, upper, comm, s), "ncclRecv");
+    ck(a.Recv(from_lo, from_lo_bytes, RcclApi::kInt8, lower, comm, s), "ncclRecv");
+    ck(a.GroupEnd(), "ncclGroupEnd");
+  }
+  void allreduce_max_f64(double* dev, size_t count, hipStream_t s) override {
+    ck(rccl_api().AllReduce(dev, dev, count, RcclApi::kFloat64, RcclApi::kMax, comm, s), "ncclAllReduce");
+  }
+  void allreduce_sum_f64(double* dev, size_t count, hipStream_t s) override {
+    ck(rccl_api().AllReduce(dev, dev, count, RcclApi::kFloat64, RcclApi::kSum, comm, s), "ncclAllReduce");
+  }
+  void allgather(const void* in, void* out, size_t bytes, hipStream_t s) override {
+    ck(rccl_api().AllGather(in, out, bytes, RcclApi::kInt8, comm, s), "ncclAllGather");
+  }
+};
+
+}  // namespace chem

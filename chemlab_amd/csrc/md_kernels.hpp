@@ -52,13 +52,21 @@ struct DevCtl {
   int alive;                          // reaction resolve: pairs still undecided
   int accepted;                       // reaction resolve: accepted events
   long long nlist_entries;
+  double step_m2;                     // max |dx|^2 of the step (after the cross-rank max in DD mode)
+  int mig_error;                      // a particle left its slab by more than one layer / migration buffer overflow
+  int bonded_missing;                 // a bonded partner is neither owned nor a ghost on this rank
 };
 
 template <typename R> struct Box {
   R L[3], invL[3];
-  int nc[3];       // cells per axis (0 => brute-force list build)
+  int nc[3];       // cells per axis (0 => brute-force list build); in z-ghost mode nc[2] = own layers + 2
   int ncell;
-  R cell_inv[3];   // nc/L
+  R cell_inv[3];   // cells per unit length (global grid)
+  // slab domain decomposition along z (chem_comm_init): layer 0 and nc[2]-1 are ghost layers that
+  // hold copies of the neighbour ranks' boundary layers; x and y stay periodic in-kernel
+  int zghost;      // 0: z periodic in-kernel, 1: ghost layers
+  int z0g, nzg;    // first own global layer, global layer count
+  R shz_lo, shz_hi;  // shift to apply to the lower / upper ghost layer (+-Lz across the periodic boundary)
 };
 
 // Non-bonded parameters of one type pair, pre-multiplied (gromacs_topology.py:715-721,
@@ -145,61 +153,109 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
 }
 
 // one block: fold the step's per-block max displacement into the accumulated distance and
-// decide whether the Verlet list must be rebuilt (VelocityVerlet::run)
+// decide whether the Verlet list must be rebuilt (VelocityVerlet::run).
+// phase 3: both (single GPU); phase 1: fold only -> ctl->step_m2 (then max over ranks);
+// phase 2: decide from ctl->step_m2.
 template <typename R>
-__global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned long long* __restrict__ blockmax, int nblk, double half_skin, int criterion) {
+__global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned long long* __restrict__ blockmax, int nblk, double half_skin, int criterion, int phase) {
   unsigned long long m = 0;
-  for (int k = threadIdx.x; k < nblk; k += 1024) { unsigned long long b = blockmax[k]; blockmax[k] = 0ull; m = b > m ? b : m; }
-  for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+  if (phase & 1) {
+    for (int k = threadIdx.x; k < nblk; k += 1024) { unsigned long long b = blockmax[k]; blockmax[k] = 0ull; m = b > m ? b : m; }
+    for (int o = 32; o > 0; o >>= 1) { unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+  }
   __shared__ unsigned long long wm[16];
   if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 16; ++k) m = wm[k] > m ? wm[k] : m;
-    const double m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
-    double acc = criterion ? sqrt(m2) : ctl->acc_maxdist + sqrt(m2);
-    const int need = (acc > half_skin) || ctl->force_rebuild;
-    if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
-    ctl->acc_maxdist = acc;
-    ctl->need_rebuild = need;
+    double m2;
+    if (phase & 1) {
+      for (int k = 1; k < 16; ++k) m = wm[k] > m ? wm[k] : m;
+      m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
+      ctl->step_m2 = m2;
+    } else m2 = ctl->step_m2;
+    if (phase & 2) {
+      double acc = criterion ? sqrt(m2) : ctl->acc_maxdist + sqrt(m2);
+      const int need = (acc > half_skin) || ctl->force_rebuild;
+      if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
+      ctl->acc_maxdist = acc;
+      ctl->need_rebuild = need;
+    }
   }
 }
 
 // =======================================================================================
 // K1  cell binning + canonical sort (storage.decompose(), start_simulation.py:158-171)
 // =======================================================================================
+// migration buffer of one direction (SoA, fixed capacity, count in front): particles that left the
+// slab travel to the neighbour rank with their full state
+template <typename R> struct MigBuf { int* count; Vec4<R>* x; Vec4<R>* v; int4* img; int* tag; int cap; };
+
 template <typename R>
-__global__ __launch_bounds__(256) void k_bin(int n, Vec4<R>* __restrict__ x4, int4* __restrict__ img4, Box<R> box,
+__global__ __launch_bounds__(256) void k_bin(int i0, int n, Vec4<R>* __restrict__ x4, const Vec4<R>* __restrict__ v4, const int* __restrict__ tag,
+                                             int4* __restrict__ img4, Box<R> box,
                                              int* __restrict__ cell_cnt, int* __restrict__ cell_of,
-                                             int* __restrict__ slot_of, const DevCtl* ctl) {
+                                             int* __restrict__ slot_of, MigBuf<R> mdn, MigBuf<R> mup, DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+  for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i0 + n; i += gridDim.x * blockDim.x) {
     Vec4<R> x = x4[i];
     int4 im = img4[i];
     R* p = &x.x; int* ip = &im.x;
     int c[3];
+    const int nd = box.zghost ? 2 : 3;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      R s = floor_r(p[d] * box.invL[d]);
-      if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
-      if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
-      if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
-      int cc = (int)(p[d] * box.cell_inv[d]);
-      int ncd = box.nc[d] > 0 ? box.nc[d] : 1;
-      cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
-      c[d] = cc;
+      if (d < nd) {
+        R s = floor_r(p[d] * box.invL[d]);
+        if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
+        if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
+        if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
+        int cc = (int)(p[d] * box.cell_inv[d]);
+        int ncd = box.nc[d] > 0 ? box.nc[d] : 1;
+        cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
+        c[d] = cc;
+      }
+    }
+    int dir = 0;   // 0 stays, -1 leaves downwards, +1 upwards
+    if (box.zghost) {
+      // global layer of the (unfolded) z; the slab owns layers [z0g, z0g + nc[2]-2)
+      int gz = (int)floor_r(p[2] * box.cell_inv[2]);
+      const int own = box.nc[2] - 2;
+      const int rel = gz - box.z0g;
+      if (rel >= 0 && rel < own) c[2] = rel + 1;
+      else if (rel == -1) dir = -1;
+      else if (rel == own) dir = 1;
+      else { ctl->mig_error = 1; c[2] = rel < 0 ? 1 : own; }   // moved by more than one layer: impossible within skin/2
+      if (dir) {
+        // crossing the global periodic boundary: shift into the neighbour's frame
+        if (p[2] < (R)0) { p[2] += box.L[2]; ip[2] -= 1; } else if (p[2] >= box.L[2]) { p[2] -= box.L[2]; ip[2] += 1; }
+      }
     }
     x4[i] = x; img4[i] = im;
+    if (dir) {
+      const MigBuf<R>& mb = dir < 0 ? mdn : mup;
+      const int k = atomicAdd(mb.count, 1);
+      if (k < mb.cap) { mb.x[k] = x; mb.v[k] = v4[i]; mb.img[k] = im; mb.tag[k] = tag[i]; } else ctl->mig_error = 2;
+      cell_of[i] = -1;
+      continue;
+    }
     int cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
     cell_of[i] = cid;
     slot_of[i] = atomicAdd(&cell_cnt[cid], 1);
   }
 }
 
+// arrivals of a migration exchange are appended behind the current particles
+template <typename R>
+__global__ __launch_bounds__(256) void k_append_arrivals(MigBuf<R> in, int count, int dst0, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
+                                                        int* __restrict__ tag, int4* __restrict__ img4) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= count) return;
+  x4[dst0 + k] = in.x[k]; v4[dst0 + k] = in.v[k]; tag[dst0 + k] = in.tag[k]; img4[dst0 + k] = in.img[k];
+}
 
 // single-block exclusive scan of cell counts -> cell_start[0..ncell]; zeroes cell_cnt for next time.
 // 4096-element tiles, coalesced, thread-local 4-scan + wave shuffle scan + 16 wave partials.
-__global__ __launch_bounds__(1024) void k_scan_cells(int ncell, int* __restrict__ cell_cnt, int* __restrict__ cell_start,
+__global__ __launch_bounds__(1024) void k_scan_cells(int ncell, int base0, int* __restrict__ cell_cnt, int* __restrict__ cell_start,
                                                      const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
   __shared__ int wsum[16];
@@ -219,21 +275,23 @@ __global__ __launch_bounds__(1024) void k_scan_cells(int ncell, int* __restrict_
     __syncthreads();
     int woff = 0, tot = 0;
     for (int k = 0; k < 16; ++k) { if (k < w) woff += wsum[k]; tot += wsum[k]; }
-    int run = carry_s + woff + incl - sum;
+    int run = base0 + carry_s + woff + incl - sum;
 #pragma unroll
     for (int u = 0; u < 4; ++u) { if (i0 + u < ncell) cell_start[i0 + u] = run; run += v[u]; }
     __syncthreads();
     if (threadIdx.x == 0) carry_s += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) cell_start[ncell] = carry_s;
+  if (threadIdx.x == 0) cell_start[ncell] = base0 + carry_s;
 }
 
-__global__ __launch_bounds__(256) void k_place(int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of,
+__global__ __launch_bounds__(256) void k_place(int i0, int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of,
                                                const int* __restrict__ cell_start, int* __restrict__ perm, const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    perm[cell_start[cell_of[i]] + slot_of[i]] = i;
+  for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i0 + n; i += gridDim.x * blockDim.x) {
+    const int c = cell_of[i];
+    if (c >= 0) perm[cell_start[c] + slot_of[i]] = i;   // c < 0: migrated away
+  }
 }
 
 // One wave per cell: rank the members by tag (canonical order inside a cell => the whole pipeline
@@ -272,18 +330,71 @@ __global__ __launch_bounds__(256) void k_sort_gather(int ncell, const int* __res
 }
 
 template <typename R>
-__global__ __launch_bounds__(256) void k_copyback(int n, const Vec4<R>* __restrict__ x4o, const Vec4<R>* __restrict__ v4o,
+__global__ __launch_bounds__(256) void k_copyback(const int* __restrict__ cell_start, int c_first, int c_last, const Vec4<R>* __restrict__ x4o, const Vec4<R>* __restrict__ v4o,
                                                   const int* __restrict__ tago,
                                                   const int4* __restrict__ img4o, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                   int* __restrict__ tag, int4* __restrict__ img4,
                                                   int* __restrict__ rtag, Vec4<R>* __restrict__ x0, const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+  const int kbeg = cell_start[c_first], kend = cell_start[c_last];   // the own (non-ghost) cells
+  for (int k = kbeg + blockIdx.x * blockDim.x + threadIdx.x; k < kend; k += gridDim.x * blockDim.x) {
     const Vec4<R> xk = x4o[k];
     x4[k] = xk; if (x0) x0[k] = xk;
     v4[k] = v4o[k]; img4[k] = img4o[k];
     int t = tago[k]; tag[k] = t; rtag[t] = k;
   }
+}
+
+// ---- slab decomposition: ghost layers --------------------------------------------------
+// per-cell counts of the two boundary layers (what the neighbours need to lay out their ghosts)
+__global__ __launch_bounds__(256) void k_layer_counts(int nxy, int own_layers, const int* __restrict__ cell_start,
+                                                      int* __restrict__ cnt_dn, int* __restrict__ cnt_up) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > nxy) return;
+  const int c1 = nxy, cn = own_layers * nxy;   // first cell of own layer 1 / of the last own layer
+  if (k < nxy) { cnt_dn[k] = cell_start[c1 + k + 1] - cell_start[c1 + k]; cnt_up[k] = cell_start[cn + k + 1] - cell_start[cn + k]; }
+  else { cnt_dn[nxy] = cell_start[c1 + nxy] - cell_start[c1]; cnt_up[nxy] = cell_start[cn + nxy] - cell_start[cn]; }
+}
+
+// cell_start of the two ghost layers from the neighbours' per-cell counts (single block):
+// lower ghosts are right-aligned in front of the reals, upper ghosts follow them
+__global__ __launch_bounds__(1024) void k_ghost_cells(int nxy, int own_layers, const int* __restrict__ gcnt_lo, const int* __restrict__ gcnt_up,
+                                                      int* __restrict__ cell_start) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int c_up = (own_layers + 1) * nxy;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int* cnt = pass ? gcnt_up : gcnt_lo;
+    const int base_cell = pass ? c_up : 0;
+    const int start = pass ? cell_start[c_up] : cell_start[nxy] - gcnt_lo[nxy];   // upper ghosts begin where the reals end
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int w = threadIdx.x >> 6;
+    for (int b = 0; b < nxy; b += 1024) {
+      const int i = b + threadIdx.x;
+      const int v = i < nxy ? cnt[i] : 0;
+      int incl = v;
+      for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane_id() >= o) incl += t; }
+      if (lane_id() == 63) wsum[w] = incl;
+      __syncthreads();
+      int woff = 0, tot = 0;
+      for (int k = 0; k < 16; ++k) { if (k < w) woff += wsum[k]; tot += wsum[k]; }
+      if (i < nxy) cell_start[base_cell + i] = start + carry_s + woff + incl - v;
+      __syncthreads();
+      if (threadIdx.x == 0) carry_s += tot;
+      __syncthreads();
+    }
+    if (pass && threadIdx.x == 0) cell_start[c_up + nxy] = start + carry_s;
+    __syncthreads();
+  }
+}
+
+// rtag for ghost copies (only where the particle is not owned here)
+__global__ __launch_bounds__(256) void k_ghost_rtag(int g0, int ng, const int* __restrict__ tag, int* __restrict__ rtag) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ng) return;
+  const int t = tag[g0 + k];
+  atomicCAS(&rtag[t], -1, g0 + k);
 }
 
 // =======================================================================================
@@ -568,8 +679,10 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
   const int nx = box.nc[0], ny = box.nc[1], nz = box.nc[2];
   const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
   const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
-  const int cx0 = tx * HX, cy0 = ty * HY, cz0 = tz * HZ;
-  const int hx = min(HX, nx - cx0), hy = min(HY, ny - cy0), hz = min(HZ, nz - cz0);
+  // z-ghost mode: layers 1..nz-2 are own, the stencil reaches into the ghost layers 0 and nz-1
+  const int zg = box.zghost;
+  const int cx0 = tx * HX, cy0 = ty * HY, cz0 = tz * HZ + zg;
+  const int hx = min(HX, nx - cx0), hy = min(HY, ny - cy0), hz = min(HZ, nz - zg - cz0);
   const int t = threadIdx.x;
   if (t < NROW * SX) {
     const int r = t / SX, k = t % SX, ry = r % SY, rz = r / SY;
@@ -579,7 +692,8 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
       R shy = 0, shz = 0;
       if (ox < 0) { ox += nx; shx = -box.L[0]; } else if (ox >= nx) { ox -= nx; shx = box.L[0]; }
       if (oy < 0) { oy += ny; shy = -box.L[1]; } else if (oy >= ny) { oy -= ny; shy = box.L[1]; }
-      if (oz < 0) { oz += nz; shz = -box.L[2]; } else if (oz >= nz) { oz -= nz; shz = box.L[2]; }
+      if (zg) { shz = oz == 0 ? box.shz_lo : (oz == nz - 1 ? box.shz_hi : (R)0); }
+      else if (oz < 0) { oz += nz; shz = -box.L[2]; } else if (oz >= nz) { oz -= nz; shz = box.L[2]; }
       const int oc = (oz * ny + oy) * nx + ox;
       g = cell_start[oc]; cnt = cell_start[oc + 1] - g;
       if (k == 0) { T.rowshy[r] = shy; T.rowshz[r] = shz; }
@@ -1023,12 +1137,12 @@ __device__ __forceinline__ D3 minimgD(const BoxD& b, D3 d) {
 template <typename R> __device__ __forceinline__ D3 posD(const Vec4<R>& v) { return {(double)v.x, (double)v.y, (double)v.z}; }
 
 template <typename R, bool ENERGY>
-__global__ __launch_bounds__(256) void k_bonded(int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
+__global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
                                                 const int* __restrict__ tag, const int* __restrict__ rtag,
                                                 const int* __restrict__ bstart, const BondedEntry* __restrict__ bent,
-                                                const BondedParam* __restrict__ bpar, BoxD box, double* __restrict__ elist) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+                                                const BondedParam* __restrict__ bpar, BoxD box, double* __restrict__ elist, DevCtl* ctl) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i0 + n) return;
   const int tg = tag[i];
   const int e0 = bstart[tg], e1 = bstart[tg + 1];
   if (e0 == e1) return;
@@ -1041,7 +1155,9 @@ __global__ __launch_bounds__(256) void k_bonded(int n, const Vec4<R>* __restrict
     double u = 0;
     if (bp.arity == 2) {
       // tuple (t0,t1); r_ij = x_t0 - x_t1
-      const D3 x0 = posD<R>(x4[rtag[be.t0]]), x1 = posD<R>(x4[rtag[be.t1]]);
+      const int j0 = rtag[be.t0], j1 = rtag[be.t1];
+      if ((j0 | j1) < 0) { ctl->bonded_missing = 1; continue; }
+      const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]);
       const D3 d = minimgD(box, x0 - x1);
       const double r = sqrt(dot3(d, d));
       double ff = 0;
@@ -1050,7 +1166,9 @@ __global__ __launch_bounds__(256) void k_bonded(int n, const Vec4<R>* __restrict
       const double sgn = me == 0 ? 1.0 : -1.0;
       f = f + (sgn * ff) * d;
     } else if (bp.arity == 3) {
-      const D3 x0 = posD<R>(x4[rtag[be.t0]]), x1 = posD<R>(x4[rtag[be.t1]]), x2 = posD<R>(x4[rtag[be.t2]]);
+      const int j0 = rtag[be.t0], j1 = rtag[be.t1], j2 = rtag[be.t2];
+      if ((j0 | j1 | j2) < 0) { ctl->bonded_missing = 1; continue; }
+      const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]), x2 = posD<R>(x4[j2]);
       const D3 r1 = minimgD(box, x0 - x1), r2 = minimgD(box, x2 - x1);
       const double n1 = sqrt(dot3(r1, r1)), n2 = sqrt(dot3(r2, r2));
       double c = dot3(r1, r2) / (n1 * n2);
@@ -1067,8 +1185,10 @@ __global__ __launch_bounds__(256) void k_bonded(int n, const Vec4<R>* __restrict
       if (me == 0) f = f + fi; else if (me == 2) f = f + fk; else f = f - (fi + fk);
     } else {
       const BondedEntry be2 = bent[e + 1];  // quadruples occupy two consecutive entries: (t0,t1,t2,meta),(t3,-,-,-)
-      const D3 x0 = posD<R>(x4[rtag[be.t0]]), x1 = posD<R>(x4[rtag[be.t1]]), x2 = posD<R>(x4[rtag[be.t2]]), x3 = posD<R>(x4[rtag[be2.t0]]);
+      const int j0 = rtag[be.t0], j1 = rtag[be.t1], j2 = rtag[be.t2], j3 = rtag[be2.t0];
       ++e;
+      if ((j0 | j1 | j2 | j3) < 0) { ctl->bonded_missing = 1; continue; }
+      const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]), x2 = posD<R>(x4[j2]), x3 = posD<R>(x4[j3]);
       const D3 b1 = minimgD(box, x1 - x0), b2 = minimgD(box, x2 - x1), b3 = minimgD(box, x3 - x2);
       const D3 m = cross3(b1, b2), nn = cross3(b2, b3);
       const double m2 = dot3(m, m), n2 = dot3(nn, nn), lb2 = dot3(b2, b2), lb = sqrt(lb2);
@@ -1102,10 +1222,10 @@ __global__ __launch_bounds__(256) void k_bonded(int n, const Vec4<R>* __restrict
 // K11 observables (analysis.Temperature/KineticEnergy, start_simulation.py:453-493)
 // =======================================================================================
 template <typename R>
-__global__ __launch_bounds__(256) void k_kinetic(int n, const Vec4<R>* __restrict__ v4, double* __restrict__ out) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_kinetic(int i0, int n, const Vec4<R>* __restrict__ v4, double* __restrict__ out) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
   double ek = 0, px = 0, py = 0, pz = 0;
-  if (i < n) {
+  if (i < i0 + n) {
     const Vec4<R> v = v4[i];
     const double m = (double)v.w, vx = (double)v.x, vy = (double)v.y, vz = (double)v.z;
     ek = 0.5 * m * (vx * vx + vy * vy + vz * vz); px = m * vx; py = m * vy; pz = m * vz;
@@ -1139,7 +1259,7 @@ struct Candidate { int a, b, r; unsigned int h; double d2; };  // a: role type_1
 // filters, evaluates the distance criterion in fp64 without FMA contraction (bit-comparable
 // with the CPU oracle) and appends the hits with one atomic per wave (ballot compaction).
 template <typename R>
-__global__ __launch_bounds__(256) void k_react_scan(int n, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+__global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
                                                     const int* __restrict__ nlist, const int* __restrict__ nn, int S,
                                                     const int* __restrict__ state, const int* __restrict__ res_id,
                                                     const int* __restrict__ mol_id, BoxD box, const ReactSet* __restrict__ rs_g,
@@ -1158,11 +1278,11 @@ __global__ __launch_bounds__(256) void k_react_scan(int n, const Vec4<R>* __rest
   Candidate* wbuf = sbuf + (threadIdx.x >> 6) * kWaveBuf;
   int wcount = 0;   // wave-uniform
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = gid / TPP, sub = gid % TPP;
+  const int i = i0 + gid / TPP, sub = gid % TPP;
   int cnt = 0, ti = 0, si = 0, tgi = 0, ri = 0, mi = 0;
   Vec4<R> xi = mk4<R>(0, 0, 0, 0);
   const int* row = nullptr;
-  if (i < n) {
+  if (i < i0 + n) {
     xi = x4[i]; ti = (int)xi.w; tgi = tag[i]; si = state[tgi]; ri = res_id[tgi]; mi = mol_id[tgi];
     cnt = nn[i]; row = nlist + (size_t)i * S;
     // quick reject: particle cannot take part in any active reaction
@@ -1310,8 +1430,8 @@ __global__ void k_react_apply(int nc, const Candidate* __restrict__ c, const int
   const Candidate cd = c[k];
   const ReactApply ra = ras.r[cd.r];
   state[cd.a] += ra.delta_1; state[cd.b] += ra.delta_2;
-  if (ra.new_type_1 >= 0) { int i = rtag[cd.a]; x4[i].w = (R)ra.new_type_1; v4[i].w = (R)ra.new_mass_1; }
-  if (ra.new_type_2 >= 0) { int i = rtag[cd.b]; x4[i].w = (R)ra.new_type_2; v4[i].w = (R)ra.new_mass_2; }
+  if (ra.new_type_1 >= 0) { int i = rtag[cd.a]; if (i >= 0) { x4[i].w = (R)ra.new_type_1; v4[i].w = (R)ra.new_mass_1; } }
+  if (ra.new_type_2 >= 0) { int i = rtag[cd.b]; if (i >= 0) { x4[i].w = (R)ra.new_type_2; v4[i].w = (R)ra.new_mass_2; } }
   out[atomicAdd(out_count, 1)] = cd;
 }
 

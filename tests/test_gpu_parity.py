@@ -275,3 +275,55 @@ def test_modify_particle_and_errors(make_gpu):
         g.reaction_init(0)
     with pytest.raises(ChemError):
         g.list_create(5, "HARMONIC")
+
+
+# ---- slab domain decomposition, exercised on ONE GPU: the rank's lower and upper z-neighbour are
+# itself (device copies, or RCCL send/recv to self), so migration, ghost layers, the ghost-mode tile
+# tables and the candidate gather all run for real and must reproduce the single-domain oracle.
+@pytest.mark.parametrize("transport", ["dd_self", "dd_self_rccl"])
+def test_dd_self_forces_lists_and_trajectory(make_gpu, make_oracle, transport):
+    spec = W.lj_melt(n=8788, seed=31, jitter=0.08, kT=1.5)      # 13^3*4, 7 cell layers
+    spec["rebuild_criterion"] = 0
+    g, o = make_gpu(64), make_oracle()
+    g.set_option(transport, 1)
+    W.apply(spec, g, thermostat=False); W.apply(spec, o, thermostat=False)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-10
+    assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
+    og, oo = g.observe(), o.observe()
+    assert og["epot_lj"] == pytest.approx(oo["epot_lj"], rel=1e-11)
+    assert og["ekin"] == pytest.approx(oo["ekin"], rel=1e-12)
+    g.run(150); o.run(150)                                      # particles cross z = 0 / L and migrate
+    assert g.timers()["rebuilds"] >= 5
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+    assert np.array_equal(g.get_state("IMAGE"), o.get_state("IMAGE"))
+    assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < 1e-7
+
+
+def test_dd_self_reactive_polymer_parity(make_gpu, make_oracle):
+    spec = W.reactive_melt(n=8788, seed=12, interval=25)
+    g, o = make_gpu(64), make_oracle()
+    g.set_option("dd_self", 1)
+    hg, ho = W.apply(spec, g), W.apply(spec, o)
+    for _ in range(3):
+        g.run(25); o.run(25)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 2000
+    assert [e[:4] for e in eg] == [e[:4] for e in eo]
+    assert np.array_equal(g.get_list(hg["reaction_bonds"]), o.get_list(ho["reaction_bonds"]))
+    assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+    assert np.array_equal(g.get_state("TYPE"), o.get_state("TYPE"))
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+    og, oo = g.observe(), o.observe()
+    assert np.allclose(og["epot_list"], oo["epot_list"], rtol=1e-9)
+
+
+def test_dd_self_bonded_chains_fp32(make_gpu, make_oracle):
+    spec = W.polymer_melt(n_chains=256, chain_len=32, seed=3)     # 8192 beads, bonds/angles across the ghost layer
+    g, o = make_gpu(32), make_oracle()
+    g.set_option("dd_self", 1)
+    W.apply(spec, g, thermostat=False); W.apply(spec, o, thermostat=False)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[32]
+    g.run(40); o.run(40)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 2e-4
