@@ -114,6 +114,7 @@ PRODUCT_ONLY = {
     "set_nlist_capacity": (_i, [_P, _i]),
     "comm_unique_id": (_i, [C.c_char_p]),
     "comm_init": (_i, [_P, _i, _i, C.POINTER(C.c_int), C.c_char_p]),
+    "comm_init_local": (_i, [_P, _i, _i, _i]),
 }
 
 

@@ -1390,4 +1390,18 @@ int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], 
   API_END(ctx)
 }
 
+// In-process ranks (several contexts of one process, one host thread each) exchanging through a
+// shared hub: validates the multi-rank decomposition on a single GPU.  Same contract as
+// chem_comm_init, `hub_id` names the group.
+int chem_comm_init_local(chem_ctx* ctx, int nranks, int rank, int hub_id) {
+  API_BEGIN
+  Ctx& c = CTX;
+  REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, CHEM_EINVAL, "comm_init_local: rank/nranks");
+  REQUIRE(!c.dd_on && c.particles_dirty, CHEM_ESTATE, "comm_init_local must precede the first run");
+  c.tr.reset(new LocalTransport(nranks, rank, hub_id));
+  c.dd_on = true; c.P = nranks; c.rk = rank; c.geom_dirty = true;
+  return 0;
+  API_END(ctx)
+}
+
 }  // extern "C"

@@ -12,7 +12,11 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -118,6 +122,83 @@ struct RcclTransport : Transport {
   }
   void allgather(const void* in, void* out, size_t bytes, hipStream_t s) override {
     ck(rccl_api().AllGather(in, out, bytes, RcclApi::kInt8, comm, s), "ncclAllGather");
+  }
+};
+
+
+// ---- in-process transport: several contexts (ranks) of ONE process, each driven by its own host
+// thread, exchange through a shared hub with device-to-device copies.  Used to validate the
+// multi-rank logic (distinct slabs, real neighbours, gathers) on a single GPU; also a way to run
+// several domains on one device.
+struct LocalHub {
+  int P = 0;
+  std::mutex mu; std::condition_variable cv;
+  int arrived = 0; long long gen = 0;
+  struct Post { const void* a = nullptr; size_t ab = 0; const void* b = nullptr; size_t bb = 0; };
+  std::vector<Post> post;
+  std::vector<double> red;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(mu);
+    const long long g = gen;
+    if (++arrived == P) { arrived = 0; ++gen; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != g; });
+  }
+};
+
+inline std::shared_ptr<LocalHub> local_hub(int id, int P) {
+  static std::mutex m; static std::map<int, std::shared_ptr<LocalHub>> hubs;
+  std::lock_guard<std::mutex> lk(m);
+  auto& h = hubs[id];
+  if (!h) { h = std::make_shared<LocalHub>(); h->P = P; h->post.resize(P); }
+  if (h->P != P) throw ChemError(CHEM_EINVAL, "local hub: rank count mismatch");
+  return h;
+}
+
+struct LocalTransport : Transport {
+  std::shared_ptr<LocalHub> hub;
+  LocalTransport(int nr, int rk, int hub_id) { nranks = nr; rank = rk; hub = local_hub(hub_id, nr); }
+  static void ck(hipError_t e) { if (e != hipSuccess) throw ChemError(CHEM_ECOMM, std::string("local transport: ") + hipGetErrorString(e)); }
+  void exchange(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes, void* from_lo,
+                size_t from_lo_bytes, int lower, int upper, hipStream_t s) override {
+    ck(hipStreamSynchronize(s));
+    hub->post[rank] = LocalHub::Post{dn, dn_bytes, up, up_bytes};
+    hub->barrier();
+    const LocalHub::Post& pu = hub->post[upper]; const LocalHub::Post& pl = hub->post[lower];
+    if (pu.ab != from_up_bytes || pl.bb != from_lo_bytes) throw ChemError(CHEM_ECOMM, "local transport: message size mismatch");
+    if (from_up_bytes) ck(hipMemcpyAsync(from_up, pu.a, from_up_bytes, hipMemcpyDeviceToDevice, s));
+    if (from_lo_bytes) ck(hipMemcpyAsync(from_lo, pl.b, from_lo_bytes, hipMemcpyDeviceToDevice, s));
+    ck(hipStreamSynchronize(s));
+    hub->barrier();
+  }
+  void allreduce(double* dev, size_t count, hipStream_t s, bool is_max) {
+    std::vector<double> v(count);
+    ck(hipMemcpyAsync(v.data(), dev, count * sizeof(double), hipMemcpyDeviceToHost, s)); ck(hipStreamSynchronize(s));
+    {
+      std::lock_guard<std::mutex> lk(hub->mu);
+      if (hub->red.size() != count * (size_t)nranks) hub->red.assign(count * (size_t)nranks, 0.0);
+      for (size_t k = 0; k < count; ++k) hub->red[(size_t)rank * count + k] = v[k];
+    }
+    hub->barrier();
+    for (size_t k = 0; k < count; ++k) {
+      double r = hub->red[k];
+      for (int q = 1; q < nranks; ++q) { const double o = hub->red[(size_t)q * count + k]; r = is_max ? (o > r ? o : r) : r + o; }
+      v[k] = r;
+    }
+    ck(hipMemcpyAsync(dev, v.data(), count * sizeof(double), hipMemcpyHostToDevice, s)); ck(hipStreamSynchronize(s));
+    hub->barrier();
+  }
+  void allreduce_max_f64(double* dev, size_t count, hipStream_t s) override { allreduce(dev, count, s, true); }
+  void allreduce_sum_f64(double* dev, size_t count, hipStream_t s) override { allreduce(dev, count, s, false); }
+  void allgather(const void* in, void* out, size_t bytes, hipStream_t s) override {
+    ck(hipStreamSynchronize(s));
+    hub->post[rank] = LocalHub::Post{in, bytes, nullptr, 0};
+    hub->barrier();
+    for (int q = 0; q < nranks; ++q) {
+      void* dst = (char*)out + (size_t)q * bytes;
+      if (hub->post[q].a != dst && bytes) ck(hipMemcpyAsync(dst, hub->post[q].a, bytes, hipMemcpyDeviceToDevice, s));
+    }
+    ck(hipStreamSynchronize(s));
+    hub->barrier();
   }
 };
 

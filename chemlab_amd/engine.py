@@ -20,6 +20,16 @@ def _ptr(a, typ):
     return a.ctypes.data_as(C.POINTER(typ)) if a is not None else None
 
 
+def comm_unique_id():
+    """RCCL unique id (128 bytes) for chem_comm_init; call on rank 0 and broadcast."""
+    api = _capi.load()
+    buf = C.create_string_buffer(128)
+    rc = api.comm_unique_id(buf)
+    if rc < 0:
+        raise ChemError(rc, (api.last_error(None) or b"").decode())
+    return buf.raw
+
+
 class Engine:
     def __init__(self, device=0, precision=32, api=None, ctx=None):
         """precision: 32 (fp32 arrays, fp64 bonded/reaction distance) or 64 (all fp64)."""
@@ -212,6 +222,14 @@ class Engine:
 
     def set_nlist_capacity(self, n):
         self._ck(self.api.set_nlist_capacity(self.ctx, int(n)))
+
+    def comm_init(self, nranks, rank, uid):
+        """Join the slab decomposition (node grid (1,1,nranks)); uid from comm_unique_id() on rank 0."""
+        grid = (C.c_int * 3)(1, 1, nranks)
+        self._ck(self.api.comm_init(self.ctx, nranks, rank, grid, uid))
+
+    def comm_init_local(self, nranks, rank, hub_id):
+        self._ck(self.api.comm_init_local(self.ctx, nranks, rank, hub_id))
 
     def sync(self):
         self._ck(self.api.device_sync(self.ctx))

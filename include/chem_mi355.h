@@ -234,6 +234,10 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value);
  * start_simulation.py:152-163.  uid comes from chem_comm_unique_id on rank 0. */
 int chem_comm_unique_id(char uid[128]);
 int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], const char uid[128]);
+/* Same decomposition with the ranks living in ONE process (one host thread per context) and
+ * exchanging by device-to-device copies through a hub named `hub_id`: several domains on a single
+ * GPU; used to validate the multi-rank path without a multi-GPU node. */
+int chem_comm_init_local(chem_ctx* ctx, int nranks, int rank, int hub_id);
 
 #ifdef __cplusplus
 }

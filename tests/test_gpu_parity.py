@@ -327,3 +327,95 @@ def test_dd_self_bonded_chains_fp32(make_gpu, make_oracle):
     assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[32]
     g.run(40); o.run(40)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 2e-4
+
+
+# ---- multi-rank slab decomposition with all ranks inside this process (one host thread per rank,
+# device-to-device exchange through chem_comm_init_local): distinct slabs, real neighbours,
+# migration between ranks, cross-rank candidate gather -- against the single-domain oracle.
+def _run_ranks(P, fn):
+    import threading
+    out, err = [None] * P, [None] * P
+
+    def work(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:   # noqa: BLE001
+            err[r] = e
+    th = [threading.Thread(target=work, args=(r,)) for r in range(P)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+_HUB = [100]
+
+
+@pytest.mark.parametrize("P,n", [(2, 8788), (3, 8788), (4, 16384)])
+def test_dd_multi_rank_in_process_lj(make_gpu, make_oracle, P, n):
+    spec = W.lj_melt(n=n, seed=33, jitter=0.08, kT=1.5)
+    spec["rebuild_criterion"] = 0
+    o = make_oracle()
+    W.apply(spec, o, thermostat=False)
+    o.run(0)
+    f0 = o.get_state("FORCE")
+    vp0 = o.get_verlet_pairs()
+    e0 = o.observe()
+    o.run(120)
+    engs = [make_gpu(64) for _ in range(P)]
+    _HUB[0] += 1
+    hub = _HUB[0]
+
+    def rank(r):
+        g = engs[r]
+        g.comm_init_local(P, r, hub)
+        W.apply(spec, g, thermostat=False)
+        g.run(0)
+        res = dict(f=g.get_state("FORCE"), vp=g.get_verlet_pairs(), obs=g.observe())
+        g.run(120)
+        res.update(x=g.get_state("POS_UNFOLDED"), v=g.get_state("VEL"), img=g.get_state("IMAGE"), reb=g.timers()["rebuilds"])
+        return res
+    out = _run_ranks(P, rank)
+    for r in range(P):
+        assert rel_err(out[r]["f"], f0) < 1e-10
+        assert np.array_equal(out[r]["vp"], vp0)
+        assert out[r]["obs"]["epot_lj"] == pytest.approx(e0["epot_lj"], rel=1e-11)
+        assert out[r]["obs"]["ekin"] == pytest.approx(e0["ekin"], rel=1e-12)
+        assert rel_err(out[r]["x"], o.get_state("POS_UNFOLDED")) < 1e-8
+        assert np.array_equal(out[r]["img"], o.get_state("IMAGE"))
+        assert out[r]["reb"] >= 4
+
+
+def test_dd_multi_rank_in_process_reactive(make_gpu, make_oracle):
+    P = 2
+    spec = W.reactive_melt(n=8788, seed=12, interval=25)
+    o = make_oracle()
+    ho = W.apply(spec, o)
+    for _ in range(3):
+        o.run(25)
+    engs = [make_gpu(64) for _ in range(P)]
+    _HUB[0] += 1
+    hub = _HUB[0]
+
+    def rank(r):
+        g = engs[r]
+        g.comm_init_local(P, r, hub)
+        h = W.apply(spec, g)
+        for _ in range(3):
+            g.run(25)
+        return dict(ev=sorted_events(g.get_events()), bonds=g.get_list(h["reaction_bonds"]), st=g.get_state("STATE"),
+                    ty=g.get_state("TYPE"), x=g.get_state("POS_UNFOLDED"), el=g.observe()["epot_list"])
+    out = _run_ranks(P, rank)
+    eo = sorted_events(o.get_events())
+    assert len(eo) > 2000
+    for r in range(P):
+        assert [e[:4] for e in out[r]["ev"]] == [e[:4] for e in eo]
+        assert np.array_equal(out[r]["bonds"], o.get_list(ho["reaction_bonds"]))
+        assert np.array_equal(out[r]["st"], o.get_state("STATE"))
+        assert np.array_equal(out[r]["ty"], o.get_state("TYPE"))
+        assert rel_err(out[r]["x"], o.get_state("POS_UNFOLDED")) < 1e-8
+        assert np.allclose(out[r]["el"], o.observe()["epot_list"], rtol=1e-9)
