@@ -72,7 +72,7 @@ def main():
     from chemlab_amd.engine import Engine
 
     spec = W.reactive_melt(n=a.n, rho=a.rho, interval=a.interval, seed=2)
-    if world > 1:
+    if world > 1 or os.environ.get("CHEM_FORCE_DD"):   # CHEM_FORCE_DD: exercise the RCCL slab path with one rank
         from chemlab_amd import multigpu
         return multigpu.bench_main(a, spec, rank, local_rank, world)
 

@@ -201,34 +201,26 @@ __global__ __launch_bounds__(256) void k_bin(int i0, int n, Vec4<R>* __restrict_
     int4 im = img4[i];
     R* p = &x.x; int* ip = &im.x;
     int c[3];
-    const int nd = box.zghost ? 2 : 3;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      if (d < nd) {
-        R s = floor_r(p[d] * box.invL[d]);
-        if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
-        if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
-        if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
-        int cc = (int)(p[d] * box.cell_inv[d]);
-        int ncd = box.nc[d] > 0 ? box.nc[d] : 1;
-        cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
-        c[d] = cc;
-      }
+      R s = floor_r(p[d] * box.invL[d]);
+      if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
+      if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
+      if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
+      int cc = (int)(p[d] * box.cell_inv[d]);
+      int ncd = (d == 2 && box.zghost) ? box.nzg : (box.nc[d] > 0 ? box.nc[d] : 1);
+      cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
+      c[d] = cc;
     }
     int dir = 0;   // 0 stays, -1 leaves downwards, +1 upwards
     if (box.zghost) {
-      // global layer of the (unfolded) z; the slab owns layers [z0g, z0g + nc[2]-2)
-      int gz = (int)floor_r(p[2] * box.cell_inv[2]);
-      const int own = box.nc[2] - 2;
-      const int rel = gz - box.z0g;
-      if (rel >= 0 && rel < own) c[2] = rel + 1;
-      else if (rel == -1) dir = -1;
-      else if (rel == own) dir = 1;
-      else { ctl->mig_error = 1; c[2] = rel < 0 ? 1 : own; }   // moved by more than one layer: impossible within skin/2
-      if (dir) {
-        // crossing the global periodic boundary: shift into the neighbour's frame
-        if (p[2] < (R)0) { p[2] += box.L[2]; ip[2] -= 1; } else if (p[2] >= box.L[2]) { p[2] -= box.L[2]; ip[2] += 1; }
-      }
+      // c[2] is the global layer of the folded z; the slab owns layers [z0g, z0g + own)
+      const int own = box.nc[2] - 2, gz = c[2];
+      const int gu = (box.z0g + own) % box.nzg, gd = (box.z0g - 1 + box.nzg) % box.nzg;
+      if (gz >= box.z0g && gz < box.z0g + own) c[2] = gz - box.z0g + 1;
+      else if (gz == gu) dir = 1;
+      else if (gz == gd) dir = -1;
+      else { ctl->mig_error = 1; c[2] = 1; }   // moved by more than one layer: impossible within skin/2
     }
     x4[i] = x; img4[i] = im;
     if (dir) {

@@ -1,0 +1,121 @@
+"""Multi-GPU host plumbing: one process per GPU (torch.distributed.run), spatial slab decomposition
+along z inside the library, ghost layers over RCCL point-to-point (xGMI).
+
+torch.distributed is used ONLY as the rendezvous (gloo, CPU tensors): broadcasting the RCCL
+unique id, barriers and the max-over-ranks of the timing.  The data path (halo exchange, the
+displacement max, the candidate gather) is RCCL inside libchem_mi355.so.
+
+Reference: ChemLab picks the process grid with espressopp.tools.decomp.nodeGrid(MPI size) and lets
+storage.DomainDecomposition do the rest (src/start_simulation.py:152-163).
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+
+def node_grid(nranks):
+    """Process grid of this build: slabs along z (the reference's nodeGrid returns a 3-D grid; the
+    in-kernel periodic wrap in x/y keeps ghost traffic to two neighbours per rank)."""
+    return (1, 1, int(nranks))
+
+
+def slab_layers(nz_global, nranks):
+    """[z0, z1) cell layers owned by each rank -- mirrors CtxT::setup_box in chem_api.hip."""
+    base, rem = divmod(int(nz_global), int(nranks))
+    if base < 2:
+        raise ValueError("fewer than 2 cell layers per rank along z: %d layers / %d ranks" % (nz_global, nranks))
+    out, z = [], 0
+    for r in range(nranks):
+        h = base + (1 if r < rem else 0)
+        out.append((z, z + h))
+        z += h
+    return out
+
+
+def owner_of(z, box_z, rc, skin, nranks):
+    """Rank owning coordinate(s) z (folded into the box first)."""
+    nz = int(np.floor(box_z / (rc + skin)))
+    layers = slab_layers(nz, nranks)
+    zf = np.mod(np.asarray(z, dtype=np.float64), box_z)
+    gz = np.clip(np.floor(zf * nz / box_z).astype(np.int64), 0, nz - 1)
+    bounds = np.array([a for a, _ in layers] + [nz])
+    return np.searchsorted(bounds, gz, side="right") - 1
+
+
+def init_process_group():
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    return dist
+
+
+def broadcast_bytes(dist, payload, src=0):
+    obj = [payload if dist.get_rank() == src else None]
+    dist.broadcast_object_list(obj, src=src)
+    return obj[0]
+
+
+def max_over_ranks(dist, value):
+    import torch
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def make_engine(rank, local_rank, world, precision=32):
+    """Engine of this rank, joined to the decomposition (RCCL communicator over all ranks)."""
+    from .engine import Engine, comm_unique_id
+    dist = init_process_group()
+    eng = Engine(device=local_rank, precision=precision)
+    uid = broadcast_bytes(dist, comm_unique_id() if rank == 0 else None)
+    eng.comm_init(world, rank, uid)
+    return eng, dist
+
+
+def device_sync(eng, local_rank):
+    eng.sync()
+    try:   # the bench contract brackets the timed region with torch.cuda.synchronize() as well
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(local_rank)
+    except Exception:
+        pass
+
+
+def bench_main(a, spec, rank, local_rank, world):
+    """bench.py for N > 1: strong scaling of the same 1M-particle box over `world` slabs."""
+    from . import workloads as W
+    eng, dist = make_engine(rank, local_rank, world, a.precision)
+    W.apply(spec, eng)
+    if a.tpp:
+        eng.set_option("tpp", a.tpp)
+    for kv in getattr(a, "opt", []):
+        k, v = kv.split("=")
+        eng.set_option(k, float(v))
+    eng.run(a.warmup)
+    device_sync(eng, local_rank)
+    dist.barrier()
+    t0 = time.perf_counter()
+    eng.run(a.steps)
+    device_sync(eng, local_rank)
+    dist.barrier()
+    wall = max_over_ranks(dist, time.perf_counter() - t0)
+    nev = len(eng.get_events())
+    if rank == 0:
+        sps = a.steps / wall
+        out = dict(metric="MD steps/sec, 1M-particle reactive LJ melt", value=sps, unit="steps/s", n_gpus=world,
+                   steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * wall / a.steps, higher_is_better=True,
+                   scaling="strong", vs_baseline=None, dtype="f32" if a.precision == 32 else "f64", data="synthetic",
+                   config=dict(workload="C5 reactive LJ melt (chain_growth_catalytic shape): %d particles, rho*=%.4g, rc=2.5, skin=0.3, dt=0.005, Langevin gamma=5 T=0.5, 4 reactions every %d steps"
+                                        % (a.n, a.rho, a.interval),
+                               particles=a.n, reaction_interval=a.interval, reaction_events_total=nev,
+                               tau_per_day=sps * spec["dt"] * 86400,
+                               parallelism="spatial slab decomposition along z over %d GPUs, RCCL ghost-layer exchange" % world))
+        print(json.dumps(out))
+    dist.barrier()
+    eng.close()
+    return 0

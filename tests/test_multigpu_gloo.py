@@ -1,0 +1,65 @@
+"""world_size-2 gloo test (CPU): the host-side plumbing of the N>1 path -- rendezvous, unique-id
+broadcast, slab ownership, max-over-ranks timing.  The device data path (RCCL halo) is covered on
+the GPU by the self / in-process multi-rank parity tests."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from chemlab_amd import multigpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from chemlab_amd import multigpu, workloads as W
+dist = multigpu.init_process_group()
+rank, world = dist.get_rank(), dist.get_world_size()
+uid = multigpu.broadcast_bytes(dist, bytes(range(128)) if rank == 0 else None)
+assert uid == bytes(range(128))
+spec = W.reactive_melt(n=8788, seed=5)
+own = multigpu.owner_of(spec["pos"][:, 2], spec["box"][2], spec["rc"], spec["skin"], world)
+mine = int((own == rank).sum())
+import torch
+t = torch.tensor([mine], dtype=torch.int64)
+dist.all_reduce(t)
+assert int(t[0]) == spec["n"], (int(t[0]), spec["n"])          # every particle has exactly one owner
+mx = multigpu.max_over_ranks(dist, 1.0 + rank)
+assert mx == float(world)
+dist.barrier()
+print(json.dumps(dict(rank=rank, mine=mine)))
+'''
+
+
+def test_slab_layers_cover_the_box():
+    for nz, p in [(38, 8), (38, 4), (38, 2), (7, 3), (9, 4), (16, 8)]:
+        lay = multigpu.slab_layers(nz, p)
+        assert lay[0][0] == 0 and lay[-1][1] == nz
+        assert all(a[1] == b[0] for a, b in zip(lay, lay[1:]))
+        assert all(2 <= z1 - z0 for z0, z1 in lay)
+        assert max(z1 - z0 for z0, z1 in lay) - min(z1 - z0 for z0, z1 in lay) <= 1
+    assert multigpu.node_grid(8) == (1, 1, 8)
+
+
+def test_owner_of_matches_layers():
+    own = multigpu.owner_of(np.array([0.0, 5.59, 5.61, 21.0, -0.1, 22.0]), 21.84, 2.5, 0.3, 3)   # 7 layers of 3.12: (0,3),(3,5),(5,7)
+    assert own.tolist() == [0, 0, 0, 2, 2, 0]
+
+
+def test_two_rank_gloo_rendezvous_and_partition(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    import socket
+    with socket.socket() as sk:          # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 2
