@@ -1,0 +1,259 @@
+"""Topology -> particle properties, bonded lists, exclusions and interactions.
+
+Behaviour of /root/reference/src/chemlab/gromacs_topology.py for the in-scope func codes (SURVEY.md
+Appendix B): LJ `func 1`, tabulated `func 8`, harmonic bonds `1`, FENE `7`, harmonic angles `1`,
+cosine angles `11`, dihedrals `1`/`3`.  Type ids: first-seen order over [ molecules ], then the
+remaining [ atomtypes ] in FILE order (the reference's py2 dict order is not reproducible
+and type ids are internal labels only).  Exclusions: bonds + neighbours up to `nrexcl` bonds away,
+with the atom-id offset per molecule type done correctly (the reference's offset bug is
+not copied; single-molecule-type inputs give identical lists)."""
+import collections
+import math
+import os
+
+from . import files_io, tables
+
+
+def convertc6c12(c6, c12, cr):
+    """(c6, c12) -> (sigma, epsilon) for combination rule 1 (gromacs_topology.py:110-121)."""
+    if cr == 1:
+        if c6 == 0.0 or c12 == 0.0:
+            return 0.0, 0.0
+        sig = (c12 / c6) ** (1.0 / 6.0)
+        return sig, c6 / (4.0 * sig ** 6)
+    return c6, c12
+
+
+def combination(sig_1, eps_1, sig_2, eps_2, cr):
+    """rule 2: arithmetic sigma; otherwise geometric sigma; epsilon always geometric (:452-460)."""
+    sig = 0.5 * (sig_1 + sig_2) if cr == 2 else math.sqrt(sig_1 * sig_2)
+    return sig, math.sqrt(eps_1 * eps_2)
+
+
+class GromacsTopology(object):
+    def __init__(self, input_topol, generate_exclusions=True):
+        self.gt = files_io.GROMACSTopologyFile(input_topol) if isinstance(input_topol, str) else input_topol
+        self.generate_exclusions = generate_exclusions
+        self.atoms = {}
+        self.bonds, self.angles, self.dihedrals, self.pairs = [collections.OrderedDict() for _ in range(4)]
+        self.exclusions = set()
+        self.atomsym_atomtype = collections.OrderedDict()
+
+    def read(self):
+        if self.gt.defaults is None:
+            self.gt.read()
+        self._prepare_data()
+        return self
+
+    # molecule replication: ids are 1-based and contiguous
+    def _prepare_data(self):
+        gt = self.gt
+        cr = gt.defaults["combinationrule"]
+        offset = 0
+        for mol_name, n_mols in gt.molecules:
+            md = gt.molecules_data[mol_name]
+            atoms = md.get("atoms", {})
+            n_atoms = len(atoms)
+            per_atom = {}
+            for at_id in sorted(atoms):
+                a = atoms[at_id]
+                at = gt.atomtypes[a.atom_type]
+                if a.atom_type not in self.atomsym_atomtype:
+                    self.atomsym_atomtype[a.atom_type] = len(self.atomsym_atomtype)
+                sig, eps = convertc6c12(at["sigma"], at["epsilon"], cr)
+                per_atom[at_id] = {"type": a.atom_type, "type_id": self.atomsym_atomtype[a.atom_type], "sig": sig, "eps": eps,
+                                   "state": at.get("state", 0), "charge": a.charge if a.charge else at["charge"],
+                                   "mass": a.mass if a.mass else at["mass"], "name": a.name, "chain_name": a.chain_name,
+                                   "chain_idx": a.chain_idx, "molecule_name": mol_name}
+            for mol in range(n_mols):
+                for k, v in per_atom.items():
+                    self.atoms[offset + k + mol * n_atoms] = v
+            for name, dst in (("bonds", self.bonds), ("angles", self.angles), ("dihedrals", self.dihedrals), ("pairs", self.pairs)):
+                for ids, params in md.get(name, {}).items():
+                    for mol in range(n_mols):
+                        dst[tuple(offset + i + mol * n_atoms for i in ids)] = params
+            if self.generate_exclusions and md.get("bonds"):
+                mol_excl = generate_exclusions(list(md["bonds"].keys()), gt.moleculetype[mol_name])
+                for mol in range(n_mols):
+                    for l in mol_excl:
+                        self.exclusions.add(tuple(sorted(offset + i + mol * n_atoms for i in l)))
+            offset += n_mols * n_atoms
+        for k, v in gt.nonbond_params.items():
+            if v["func"] == 1 and cr == 1 and v["params"]:
+                v["params"][0], v["params"][1] = convertc6c12(float(v["params"][0]), float(v["params"][1]), cr)
+        for name in gt.atomtypes:        # remaining types (needed by reactions that create them)
+            if name not in self.atomsym_atomtype:
+                self.atomsym_atomtype[name] = len(self.atomsym_atomtype)
+        self.used_atomsym_atomtype = self.atomsym_atomtype
+        self.atomtype_atomsym = {v: k for k, v in self.atomsym_atomtype.items()}
+
+
+def generate_exclusions(bond_list, nrexcl):
+    """Pairs of one molecule separated by at most `nrexcl` bonds (plus the bonds themselves)."""
+    adj = collections.defaultdict(set)
+    for a, b in bond_list:
+        adj[a].add(b)
+        adj[b].add(a)
+    excl = {tuple(sorted(b)) for b in bond_list}
+    for root in adj:
+        frontier, seen = {root}, {root}
+        for _ in range(nrexcl):
+            frontier = {n for f in frontier for n in adj[f]} - seen
+            seen |= frontier
+            for n in frontier:
+                excl.add(tuple(sorted((root, n))))
+    return excl
+
+
+def gen_particle_list(coordinate, topol, espressopp):
+    """props + particle rows (id, type, pos, mass, q, res_id, state, lambda_adr) (:1418-1441)."""
+    props = ["id", "type", "pos", "mass", "q", "res_id", "state", "lambda_adr"]
+    plist = []
+    for atom_id in sorted(coordinate.atoms):
+        d, t = coordinate.atoms[atom_id], topol.atoms[atom_id]
+        plist.append([atom_id, t["type_id"], espressopp.Real3D(d.position), t["mass"], t["charge"], d.chain_idx, t.get("state", 0), 1.0])
+    return props, plist
+
+
+def set_nonbonded_interactions(espressopp, system, gt, vl, lj_cutoff, tab_cutoff=None, tables_=None, table_dir="."):
+    """One VerletListLennardJones ('lj') and one VerletListTabulated ('lj-tab') for all type pairs
+    (:463-899).  A pair gets no potential when sigma <= 0 (:715)."""
+    tab_cutoff = lj_cutoff if tab_cutoff is None else tab_cutoff
+    tables_ = tables_ or []
+    cr = int(gt.gt.defaults["combinationrule"])
+    lj = espressopp.interaction.VerletListLennardJones(vl)
+    tab = espressopp.interaction.VerletListTabulated(vl)
+    has_lj = has_tab = False
+    names = list(gt.used_atomsym_atomtype)
+    for i, n1 in enumerate(names):
+        for n2 in names[i:]:
+            t1, t2 = gt.used_atomsym_atomtype[n1], gt.used_atomsym_atomtype[n2]
+            param = gt.gt.nonbond_params.get(tuple(sorted((n1, n2))))
+            table_name, sig, eps = None, -1.0, -1.0
+            if param:
+                if param["func"] == 1:
+                    sig, eps = float(param["params"][0]), float(param["params"][1])
+                elif param["func"] == 8:
+                    table_name = param["params"][0] if param["params"] else "table_%s_%s.xvg" % (n1, n2)
+                else:
+                    raise NotImplementedError("nonbond_params func %d is outside the hot-path scope (SURVEY.md 2.1 #3)" % param["func"])
+            elif n1 in tables_ and n2 in tables_:
+                table_name = "table_%s_%s.xvg" % (n1, n2)
+            else:
+                a1, a2 = gt.gt.atomtypes[n1], gt.gt.atomtypes[n2]
+                s1, e1 = convertc6c12(a1["sigma"], a1["epsilon"], cr)
+                s2, e2 = convertc6c12(a2["sigma"], a2["epsilon"], cr)
+                sig, eps = combination(s1, e1, s2, e2, cr)
+            if table_name is not None:
+                xvg = os.path.join(table_dir, table_name)
+                pot = xvg.replace(".xvg", "") + ".pot"
+                if not os.path.exists(pot):
+                    tables.convert_table(xvg, pot)
+                tab.setPotential(type1=t1, type2=t2, potential=espressopp.interaction.Tabulated(itype=1, filename=pot, cutoff=tab_cutoff))
+                has_tab = True
+            elif sig > 0.0:
+                lj.setPotential(type1=t1, type2=t2, potential=espressopp.interaction.LennardJones(epsilon=eps, sigma=sig, cutoff=lj_cutoff))
+                has_lj = True
+    if has_lj:
+        system.addInteraction(lj, "lj")
+    if has_tab:
+        system.addInteraction(tab, "lj-tab")
+    return lj if has_lj else None, tab if has_tab else None
+
+
+def _type_params(table, types_, default=None):
+    node = table
+    for t in types_:
+        node = node.get(t) if isinstance(node, dict) else None
+        if node is None:
+            return default
+    return node
+
+
+def set_bonded_interactions(espressopp, system, gt, dynamic_type_ids=()):
+    """[ bonds ] -> FixedPairList interactions (:902-1061).  Entries whose type pair can change through
+    a reaction go to ONE Types list (parameters by current types); the rest are grouped by parameters."""
+    groups, dyn = collections.OrderedDict(), []
+    typed_params = {}
+    for (b1, b2), prm in gt.bonds.items():
+        n1, n2 = gt.atoms[b1]["type"], gt.atoms[b2]["type"]
+        spec = _type_params(gt.gt.bondtypes, (n1, n2)) if not prm else {"func": int(prm[0]), "params": prm[1:]}
+        if spec is not None and not spec["params"]:
+            spec = _type_params(gt.gt.bondtypes, (n1, n2))
+        if spec is None:
+            raise RuntimeError("no bond parameters for %s-%s" % (n1, n2))
+        t1, t2 = gt.atoms[b1]["type_id"], gt.atoms[b2]["type_id"]
+        if t1 in dynamic_type_ids or t2 in dynamic_type_ids:
+            dyn.append((b1, b2))
+        else:
+            groups.setdefault((spec["func"], tuple(float(x) for x in spec["params"])), []).append((b1, b2))
+    out = {}
+
+    def pot_of(func, p):
+        if func == 1:
+            return espressopp.interaction.Harmonic(K=p[1] / 2.0, r0=p[0])       # K = k_gmx / 2 (:918)
+        if func == 7:
+            return espressopp.interaction.FENE(K=p[1], r0=0.0, rMax=p[0])
+        raise NotImplementedError("bond func %d is outside the hot-path scope" % func)
+    for k, ((func, p), bl) in enumerate(groups.items()):
+        fpl = espressopp.FixedPairList(system.storage)
+        fpl.addBonds(bl)
+        inter = (espressopp.interaction.FixedPairListHarmonic if func == 1 else espressopp.interaction.FixedPairListFENE)(system, fpl, pot_of(func, p))
+        system.addInteraction(inter, "bond_%d" % k)
+        out["bond_%d" % k] = (fpl, inter)
+    if dyn:
+        fpl = espressopp.FixedPairList(system.storage)
+        fpl.addBonds(dyn)
+        inter = espressopp.interaction.FixedPairListTypesHarmonic(system, fpl)
+        for n1, row in gt.gt.bondtypes.items():
+            for n2, spec in row.items():
+                if spec["func"] == 1 and n1 in gt.used_atomsym_atomtype and n2 in gt.used_atomsym_atomtype:
+                    p = [float(x) for x in spec["params"]]
+                    inter.setPotential(gt.used_atomsym_atomtype[n1], gt.used_atomsym_atomtype[n2], pot_of(1, p))
+        system.addInteraction(inter, "bond_dynamic")
+        out["bond_dynamic"] = (fpl, inter)
+    return out
+
+
+def set_angle_interactions(espressopp, system, gt, dynamic_type_ids=()):
+    """[ angles ] -> FixedTripleList interactions (:1069-1176): func 1 AngularHarmonic(K=k/2, theta0 rad),
+    func 11 Cosine(K, theta0 rad)."""
+    groups, dyn = collections.OrderedDict(), []
+    for ids, prm in gt.angles.items():
+        names = [gt.atoms[i]["type"] for i in ids]
+        spec = {"func": int(prm[0]), "params": prm[1:]} if prm and len(prm) > 1 else _type_params(gt.gt.angletypes, names)
+        if spec is None:
+            raise RuntimeError("no angle parameters for %s" % "-".join(names))
+        if any(gt.atoms[i]["type_id"] in dynamic_type_ids for i in ids):
+            dyn.append(ids)
+        else:
+            groups.setdefault((spec["func"], tuple(float(x) for x in spec["params"])), []).append(ids)
+
+    def pot_of(func, p):
+        if func == 1:
+            return espressopp.interaction.AngularHarmonic(K=p[1] / 2.0, theta0=p[0] * math.pi / 180.0)
+        if func == 11:
+            return espressopp.interaction.Cosine(K=p[1], theta0=p[0] * math.pi / 180.0)
+        raise NotImplementedError("angle func %d is outside the hot-path scope" % func)
+    out = {}
+    for k, ((func, p), tl) in enumerate(groups.items()):
+        ftl = espressopp.FixedTripleList(system.storage)
+        ftl.addTriples(tl)
+        cls = espressopp.interaction.FixedTripleListAngularHarmonic if func == 1 else espressopp.interaction.FixedTripleListCosine
+        inter = cls(system, ftl, pot_of(func, p))
+        system.addInteraction(inter, "angle_%d" % k)
+        out["angle_%d" % k] = (ftl, inter)
+    # one dynamic Types list also receives the angles that reactions spawn (TopologyManager.register_triplet)
+    any_dyn_types = [(n1, n2, n3, spec) for n1, a in gt.gt.angletypes.items() for n2, b in a.items() for n3, spec in b.items()
+                     if spec["func"] == 1 and all(n in gt.used_atomsym_atomtype for n in (n1, n2, n3))]
+    if dyn or (dynamic_type_ids and any_dyn_types):
+        ftl = espressopp.FixedTripleList(system.storage)
+        ftl.addTriples(dyn)
+        inter = espressopp.interaction.FixedTripleListTypesAngularHarmonic(system, ftl)
+        for n1, n2, n3, spec in any_dyn_types:
+            p = [float(x) for x in spec["params"]]
+            ids = [gt.used_atomsym_atomtype[n] for n in (n1, n2, n3)]
+            inter.setPotential(ids[0], ids[1], ids[2], pot_of(1, p))
+        system.addInteraction(inter, "angle_dynamic")
+        out["angle_dynamic"] = (ftl, inter)
+    return out

@@ -1,0 +1,900 @@
+"""py3 `espressopp`-shaped shim over the C ABI (include/chem_mi355.h).
+
+ChemLab reaches its hot path through Boost.Python objects of the external module `espressopp`
+(`import espressopp`, /root/reference/src/start_simulation.py:20).  This module exposes the subset
+of that surface the in-scope driver logic touches, with the same names, argument
+meaning and error behaviour, implemented on one `chemlab_amd.engine.Engine` per `System`.
+Everything outside the hot-path scope raises NotImplementedError naming the symbol.
+
+    import chemlab_amd.espp as espressopp
+    system = espressopp.System()
+    ...
+    integrator.run(n)          # -> chem_run(ctx, n)
+
+The engine factory is replaceable (`set_engine_factory`) so that tests can drive the very same
+driver code with the CPU oracle.
+"""
+import math
+import types
+
+import numpy as np
+
+from ..engine import Engine
+
+_factory = [lambda: Engine(device=0, precision=32)]
+
+
+def set_engine_factory(fn):
+    """fn() -> Engine-like object (tests: the CPU oracle)."""
+    _factory[0] = fn
+
+
+class Real3D(object):
+    def __init__(self, x=0.0, y=None, z=None):
+        if y is None:
+            v = list(x) if hasattr(x, "__len__") else [x, x, x]
+            x, y, z = v
+        self.v = np.array([x, y, z], dtype=np.float64)
+
+    def __getitem__(self, i):
+        return self.v[i]
+
+    def __len__(self):
+        return 3
+
+    def __iter__(self):
+        return iter(self.v)
+
+    def __mul__(self, s):
+        return Real3D(*(self.v * s))
+
+    def __repr__(self):
+        return "Real3D(%g, %g, %g)" % tuple(self.v)
+
+
+class Int3D(Real3D):
+    pass
+
+
+def _unsupported(name):
+    def ctor(*a, **k):
+        raise NotImplementedError("espressopp.%s is outside the MI355X hot-path scope (SURVEY.md 8b)" % name)
+    return ctor
+
+
+# --------------------------------------------------------------------------------------------
+class System(object):
+    """espressopp.System(): .rng .skin .bc .storage .integrator (start_simulation.py:148-163)."""
+
+    def __init__(self):
+        self.engine = _factory[0]()
+        self.rng = None
+        self.skin = 0.0
+        self.bc = None
+        self.storage = None
+        self.integrator = None
+        self.topology_manager = None
+        self._interactions = []     # (interaction, name)
+        self.max_cutoff = None
+
+    def addInteraction(self, interaction, name=None):
+        self._interactions.append((interaction, name if name is not None else "interaction_%d" % len(self._interactions)))
+
+    def getAllInteractions(self):
+        return {name: i for i, name in self._interactions}
+
+    def getNumberOfInteractions(self):
+        return len(self._interactions)
+
+    def getInteraction(self, k):
+        return self._interactions[k][0]
+
+    def getNameOfInteraction(self, k):
+        return self._interactions[k][1]
+
+
+class _RNG(object):
+    def __init__(self, seed=0):
+        self._seed = int(seed)
+
+    def seed(self, s):
+        self._seed = int(s)
+
+    def get_seed(self):
+        return self._seed
+
+
+class _OrthorhombicBC(object):
+    def __init__(self, rng, boxL):
+        self.rng = rng
+        self.boxL = Real3D(*[float(b) for b in boxL])
+
+
+class _Particle(object):
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+class _DomainDecomposition(object):
+    """storage.DomainDecomposition(system, nodeGrid, cellGrid): addParticles/decompose/getParticle/
+    modifyParticle (start_simulation.py:163-171; examples/atrp_lj/hooks.py:63-65)."""
+
+    def __init__(self, system, nodeGrid=None, cellGrid=None):
+        self.system = system
+        self.nodeGrid, self.cellGrid = nodeGrid, cellGrid
+        self._pending = []
+        self._props = None
+        self._uploaded = False
+        system.engine.set_box(list(system.bc.boxL))
+
+    def addParticles(self, plist, *props):
+        self._props = list(props)
+        self._pending.extend(plist)
+
+    def addParticle(self, pid, pos):
+        self._props = ["id", "pos"]
+        self._pending.append([pid, pos])
+
+    def decompose(self):
+        if self._uploaded or not self._pending:
+            return
+        pr = self._props
+        col = lambda name, default=None: [p[pr.index(name)] for p in self._pending] if name in pr else default
+        n = len(self._pending)
+        ids = np.array(col("id"), dtype=np.int64)
+        pos = np.array([list(p) for p in col("pos")], dtype=np.float64)
+        types = np.array(col("type", [0] * n), dtype=np.int32)
+        mass = np.array(col("mass", [1.0] * n), dtype=np.float64)
+        q = np.array(col("q", [0.0] * n), dtype=np.float64)
+        res_id = np.array(col("res_id", list(ids)), dtype=np.int32)
+        state = np.array(col("state", [0] * n), dtype=np.int32)
+        vel = None
+        if "v" in pr:
+            vel = np.array([list(p) for p in col("v")], dtype=np.float64)
+        self.system.engine.set_particles(ids, types, pos, mass, vel=vel, q=q, state=state, res_id=res_id)
+        self._uploaded = True
+        self._ids = ids
+        self._pending = []
+
+    def particleExists(self, pid):
+        return bool(np.any(self._ids == pid))
+
+    def getParticle(self, pid):
+        e = self.system.engine
+        k = int(np.searchsorted(np.sort(self._ids), pid))
+        g = lambda w: e.get_state(w)[k]
+        return _Particle(id=pid, pos=Real3D(*g("POS")), v=Real3D(*g("VEL")), f=Real3D(*g("FORCE")), type=int(g("TYPE")),
+                         mass=float(g("MASS")), state=int(g("STATE")), res_id=int(g("RESID")), imageBox=Int3D(*g("IMAGE")), q=0.0)
+
+    def modifyParticle(self, pid, prop, value):
+        self.system.engine.modify_particle(pid, {"type": "TYPE", "state": "STATE", "mass": "MASS", "res_id": "RESID"}[prop], value)
+
+
+def _node_grid(n, *a, **k):
+    """tools.decomp.nodeGrid(MPI size): this build decomposes along z only (multigpu.node_grid)."""
+    return Int3D(1, 1, int(n))
+
+
+def _cell_grid(box, node_grid, rc, skin, *a, **k):
+    """tools.decomp.cellGrid(box, nodeGrid, max_cutoff, skin): cells of edge >= rc+skin per node;
+    known answer examples/atrp_lj/single:39 -> (6, 6, 6) for box 13.40248, rc 2.0, skin 0.1."""
+    rl = rc + skin
+    ng = list(node_grid)
+    g = [int(math.floor(float(box[d]) / (rl * ng[d]))) for d in range(3)]
+    if min(g) < 1:
+        raise RuntimeError("local box too small for the cutoff + skin")
+    return Int3D(*g)
+
+
+class DynamicExcludeList(object):
+    """espressopp.DynamicExcludeList(integrator, pairs) (start_simulation.py:189); the device list
+    observes every Fixed*List by construction, observe_* only record the request."""
+
+    def __init__(self, integrator, exclusions=None):
+        self.system = integrator.system
+        self.exclusions = [tuple(p) for p in (exclusions or [])]
+        if self.exclusions:
+            self.system.engine.set_exclusions(self.exclusions)
+        self.observed = []
+
+    def exclude(self, a, b):
+        self.exclusions.append((a, b))
+        self.system.engine.set_exclusions(self.exclusions)
+
+    def observe_tuple(self, fpl):
+        self.observed.append(fpl)
+
+    observe_triple = observe_quadruple = observe_tuple
+
+    def get_list(self):
+        return [tuple(p) for p in self.system.engine.get_exclusions().tolist()]
+
+    @property
+    def size(self):
+        return len(self.system.engine.get_exclusions())
+
+
+class VerletList(object):
+    """espressopp.VerletList(system, cutoff, exclusionlist) (start_simulation.py:193-197)."""
+
+    def __init__(self, system, cutoff, exclusionlist=None):
+        self.system, self.cutoff, self.exclusionlist = system, cutoff, exclusionlist
+        system.max_cutoff = cutoff
+        system.engine.set_cutoff(cutoff, system.skin)
+
+    def totalSize(self):
+        return len(self.system.engine.get_verlet_pairs())
+
+    def get_timers(self):
+        return []
+
+
+# ---- fixed lists ---------------------------------------------------------------------------
+class _FixedList(object):
+    arity = 2
+
+    def __init__(self, storage):
+        self.system = storage.system
+        self.handle = None
+        self._pending = []
+
+    def _add(self, entries):
+        entries = [tuple(int(x) for x in e) for e in entries]
+        if self.handle is None:
+            self._pending.extend(entries)
+        elif entries:
+            self.system.engine.list_add(self.handle, entries)
+
+    def _bind(self, kind, by_types):
+        if self.handle is None:
+            self.handle = self.system.engine.list_create(self.arity, kind, by_types)
+            if self._pending:
+                self.system.engine.list_add(self.handle, self._pending)
+            self._pending = []
+        return self.handle
+
+    def _all(self):
+        if self.handle is None:
+            return list(self._pending)
+        return [tuple(r) for r in self.system.engine.get_list(self.handle).tolist()]
+
+    def totalSize(self):
+        return len(self._all())
+
+    size = totalSize
+
+
+class FixedPairList(_FixedList):
+    arity = 2
+
+    def addBonds(self, bonds):
+        self._add(bonds)
+
+    def add(self, a, b):
+        self._add([(a, b)])
+
+    def getAllBonds(self):
+        return self._all()
+
+    getBonds = getAllBonds
+
+
+class FixedTripleList(_FixedList):
+    arity = 3
+
+    def addTriples(self, t):
+        self._add(t)
+
+    def getAllTriples(self):
+        return self._all()
+
+
+class FixedQuadrupleList(_FixedList):
+    arity = 4
+
+    def addQuadruples(self, t):
+        self._add(t)
+
+    def getAllQuadruples(self):
+        return self._all()
+
+
+# ---- potentials (parameter holders) -----------------------------------------------------------
+class _Pot(object):
+    kind = None
+
+    def params(self):
+        raise NotImplementedError
+
+
+class _LennardJones(_Pot):
+    def __init__(self, epsilon=1.0, sigma=1.0, cutoff=2.5, shift="auto"):
+        self.epsilon, self.sigma, self.cutoff, self.shift = epsilon, sigma, cutoff, shift
+
+
+class _Tabulated(_Pot):
+    """interaction.Tabulated(itype, filename, cutoff): rows `r e f` of an ESPResSo++ .pot file."""
+
+    def __init__(self, itype=1, filename=None, cutoff=None):
+        if itype != 1:
+            raise NotImplementedError("Tabulated itype %r (only linear interpolation, itype=1, is in scope)" % itype)
+        self.itype, self.filename, self.cutoff = itype, filename, cutoff
+        tab = np.loadtxt(filename)
+        self.r, self.e, self.f = tab[:, 0], tab[:, 1], tab[:, 2]
+        self.r0, self.dr = float(self.r[0]), float(self.r[1] - self.r[0])
+
+
+class _Harmonic(_Pot):
+    kind = "HARMONIC"
+
+    def __init__(self, K=1.0, r0=0.0, cutoff=None, shift=0.0):
+        self.K, self.r0 = K, r0
+
+    def params(self):
+        return [self.K, self.r0]
+
+
+class _FENE(_Pot):
+    kind = "FENE"
+
+    def __init__(self, K=1.0, r0=0.0, rMax=1.0, cutoff=None, shift=0.0):
+        self.K, self.r0, self.rMax = K, r0, rMax
+
+    def params(self):
+        return [self.K, self.r0, self.rMax]
+
+
+class _AngularHarmonic(_Pot):
+    kind = "ANG_HARMONIC"
+
+    def __init__(self, K=1.0, theta0=0.0):
+        self.K, self.theta0 = K, theta0
+
+    def params(self):
+        return [self.K, self.theta0]
+
+
+class _Cosine(_Pot):
+    kind = "ANG_COSINE"
+
+    def __init__(self, K=1.0, theta0=0.0):
+        self.K, self.theta0 = K, theta0
+
+    def params(self):
+        return [self.K, self.theta0]
+
+
+class _DihedralHarmonicNCos(_Pot):
+    kind = "DIH_NCOS"
+
+    def __init__(self, K=0.0, phi0=0.0, multiplicity=1):
+        self.K, self.phi0, self.n = K, phi0, multiplicity
+
+    def params(self):
+        return [self.K, self.phi0, float(self.n)]
+
+
+class _DihedralRB(_Pot):
+    kind = "DIH_RB"
+
+    def __init__(self, K0=0.0, K1=0.0, K2=0.0, K3=0.0, K4=0.0, K5=0.0):
+        self.C = [K0, K1, K2, K3, K4, K5]
+
+    def params(self):
+        return list(self.C)
+
+
+# ---- interactions ----------------------------------------------------------------------------
+class _VerletListInteraction(object):
+    def __init__(self, vl):
+        self.vl, self.system = vl, vl.system
+        self._pots = {}
+
+    def getPotential(self, t1, t2):
+        return self._pots[(min(t1, t2), max(t1, t2))]
+
+    def getAllPotentials(self):
+        return dict(self._pots)
+
+
+class _VerletListLennardJones(_VerletListInteraction):
+    label = "lj"
+
+    def setPotential(self, type1, type2, potential):
+        self._pots[(min(type1, type2), max(type1, type2))] = potential
+        self.system.engine.nb_lj(type1, type2, potential.epsilon, potential.sigma, potential.cutoff, potential.shift == "auto")
+
+
+class _VerletListTabulated(_VerletListInteraction):
+    label = "tab"
+
+    def setPotential(self, type1, type2, potential):
+        self._pots[(min(type1, type2), max(type1, type2))] = potential
+        self.system.engine.nb_table(type1, type2, potential.r0, potential.dr, potential.e, potential.f, potential.cutoff)
+
+
+class _FixedListInteraction(object):
+    by_types = False
+
+    def __init__(self, system, flist, potential=None):
+        self.system, self.flist = system, flist
+        self.potential = potential
+        self._typed = {}
+        if potential is not None:
+            h = flist._bind(potential.kind, False)
+            system.engine.list_set_params(h, potential.params())
+
+    def setPotential(self, *args):
+        pot = args[-1]
+        types = tuple(int(t) for t in args[:-1])
+        if not self.by_types:
+            self.potential = pot
+            h = self.flist._bind(pot.kind, False)
+            self.system.engine.list_set_params(h, pot.params())
+            return
+        h = self.flist._bind(pot.kind, True)
+        self._typed[types] = pot
+        self.system.engine.list_set_params(h, pot.params(), types=types)
+
+    def getFixedPairList(self):
+        return self.flist
+
+    getFixedTripleList = getFixedQuadrupleList = getFixedPairList
+
+
+class _FixedListTypesInteraction(_FixedListInteraction):
+    by_types = True
+
+    def __init__(self, system, flist):
+        self.system, self.flist = system, flist
+        self.potential = None
+        self._typed = {}
+
+
+def _ns(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+interaction = _ns(
+    LennardJones=_LennardJones, Tabulated=_Tabulated, Harmonic=_Harmonic, FENE=_FENE,
+    AngularHarmonic=_AngularHarmonic, Cosine=_Cosine, DihedralHarmonicNCos=_DihedralHarmonicNCos, DihedralRB=_DihedralRB,
+    VerletListLennardJones=_VerletListLennardJones, VerletListTabulated=_VerletListTabulated,
+    FixedPairListHarmonic=_FixedListInteraction, FixedPairListFENE=_FixedListInteraction,
+    FixedPairListTypesHarmonic=_FixedListTypesInteraction, FixedPairListTypesFENE=_FixedListTypesInteraction,
+    FixedTripleListAngularHarmonic=_FixedListInteraction, FixedTripleListCosine=_FixedListInteraction,
+    FixedTripleListTypesAngularHarmonic=_FixedListTypesInteraction, FixedTripleListTypesCosine=_FixedListTypesInteraction,
+    FixedQuadrupleListDihedralHarmonicNCos=_FixedListInteraction, FixedQuadrupleListDihedralRB=_FixedListInteraction,
+    FixedQuadrupleListTypesDihedralHarmonicNCos=_FixedListTypesInteraction, FixedQuadrupleListTypesDihedralRB=_FixedListTypesInteraction,
+    # out of scope
+    FENELennardJones=_unsupported("interaction.FENELennardJones"), CoulombTruncated=_unsupported("interaction.CoulombTruncated"),
+    VerletListCoulombTruncated=_unsupported("interaction.VerletListCoulombTruncated"),
+    TabulatedAngular=_unsupported("interaction.TabulatedAngular"), TabulatedDihedral=_unsupported("interaction.TabulatedDihedral"),
+    FixedPairListTabulated=_unsupported("interaction.FixedPairListTabulated"),
+    FixedPairListTypesTabulated=_unsupported("interaction.FixedPairListTypesTabulated"),
+    FixedTripleListTabulatedAngular=_unsupported("interaction.FixedTripleListTabulatedAngular"),
+    FixedPairListLambdaHarmonic=_unsupported("interaction.FixedPairListLambdaHarmonic"),
+    VerletListDynamicResolutionLennardJones=_unsupported("interaction.VerletListDynamicResolutionLennardJones"),
+    MixedTabulated=_unsupported("interaction.MixedTabulated"), MultiTabulated=_unsupported("interaction.MultiTabulated"),
+)
+
+
+# ---- integrator + extensions -------------------------------------------------------------------
+class _VelocityVerlet(object):
+    """integrator.VelocityVerlet(system): .dt .step run(n) addExtension getTimers
+    (start_simulation.py:165-167,780)."""
+
+    def __init__(self, system):
+        self.system = system
+        system.integrator = self
+        self._dt = None
+        self._ext = []
+
+    @property
+    def dt(self):
+        return self._dt
+
+    @dt.setter
+    def dt(self, value):
+        self._dt = float(value)
+        self.system.engine.set_dt(value)
+
+    @property
+    def step(self):
+        return self.system.engine.step
+
+    def addExtension(self, ext):
+        self._ext.append(ext)
+        if hasattr(ext, "_connect"):
+            ext._connect(self)
+
+    def getNumberOfExtensions(self):
+        return len(self._ext)
+
+    def getExtension(self, k):
+        return self._ext[k]
+
+    def run(self, nsteps):
+        # ExtAnalyze observers fire every `interval` steps (aftIntV): split the call at those boundaries
+        e = self.system.engine
+        if self.system.storage is not None:
+            self.system.storage.decompose()
+        ana = [x for x in self._ext if isinstance(x, _ExtAnalyze)]
+        done = 0
+        while done < nsteps:
+            chunk = nsteps - done
+            for a in ana:
+                chunk = min(chunk, a.interval - (e.step % a.interval))
+            e.run(chunk)
+            done += chunk
+            for a in ana:
+                if e.step % a.interval == 0:
+                    a.perform()
+        if nsteps == 0:
+            e.run(0)
+
+    def getTimers(self):
+        t = self.system.engine.timers()
+        return [("Run", t["run_wall_s"]), ("Reaction", t["reaction_wall_s"]), ("Resort", t["rebuild_wall_s"])]
+
+
+class _LangevinThermostat(object):
+    """integrator.LangevinThermostat(system): .temperature (= T*kb), .gamma (start_simulation.py:330-336)."""
+
+    def __init__(self, system):
+        self.system = system
+        self.temperature = 0.0
+        self.gamma = 0.0
+        self.valid_types = None
+
+    def add_valid_types(self, types_):
+        raise NotImplementedError("LangevinThermostat.add_valid_types (thermal groups) is outside the hot-path scope")
+
+    def _connect(self, integrator):
+        seed = self.system.rng.get_seed() if self.system.rng is not None else 0
+        self.system.engine.thermostat_langevin(self.temperature, self.gamma, seed)
+
+
+class _TopologyParticleProperties(object):
+    def __init__(self, type=None, mass=None, q=None, **kw):
+        self.type, self.mass, self.q = type, mass, q
+
+
+class _PostProcessChangeProperty(object):
+    def __init__(self):
+        self.changes = {}
+
+    def add_change_property(self, type_id, prop):
+        self.changes[int(type_id)] = prop
+
+
+class _ReactionCutoff(object):
+    def __init__(self, cutoff):
+        self.cutoff = cutoff
+        self.min_cutoff = 0.0
+
+
+class _Reaction(object):
+    """integrator.Reaction(type_1, type_2, delta_1, delta_2, min_state_1, max_state_1, min_state_2,
+    max_state_2, rate, fpl, cutoff) (reaction_setup.py:81-92)."""
+
+    def __init__(self, type_1, type_2, delta_1, delta_2, min_state_1, max_state_1, min_state_2, max_state_2, rate, fpl, cutoff):
+        self.__dict__.update(type_1=type_1, type_2=type_2, delta_1=delta_1, delta_2=delta_2, min_state_1=min_state_1,
+                             max_state_1=max_state_1, min_state_2=min_state_2, max_state_2=max_state_2, rate=rate, fpl=fpl)
+        self._cut = _ReactionCutoff(cutoff)
+        self.intramolecular = False
+        self.intraresidual = False
+        self.is_virtual = False
+        self.active = True
+        self._pp = {}
+        self._index = None
+        self._system = None
+
+    @property
+    def cutoff(self):
+        return self._cut.cutoff
+
+    def get_reaction_cutoff(self):
+        return self._cut
+
+    def set_reaction_cutoff(self, rc):
+        raise NotImplementedError("ReactionCutoffRandom is outside the hot-path scope")
+
+    def add_postprocess(self, pp, which="type_1"):
+        if not isinstance(pp, _PostProcessChangeProperty):
+            raise NotImplementedError("post-process %s is outside the hot-path scope" % type(pp).__name__)
+        self._pp[which] = pp
+
+    def __setattr__(self, k, v):
+        object.__setattr__(self, k, v)
+        if k == "rate" and getattr(self, "_index", None) is not None:
+            self._system.engine.reaction_set_rate(self._index, v)
+
+
+class _ChemicalReaction(object):
+    """integrator.ChemicalReaction(system, vl, storage, topology_manager, interval): nearest_mode,
+    max_per_interval, add_reaction, disconnect (reaction_setup.py:416-427,506)."""
+
+    def __init__(self, system, vl, storage, topology_manager, interval):
+        self.system, self.interval = system, int(interval)
+        self.nearest_mode = False
+        self.max_per_interval = -1
+        self._reactions = []
+        self._initialised = False
+
+    def add_reaction(self, r):
+        self._reactions.append(r)
+
+    def _flush(self):
+        e = self.system.engine
+        if not self._initialised:
+            seed = self.system.rng.get_seed() if self.system.rng is not None else 0
+            e.reaction_init(self.interval, bool(self.nearest_mode), max(int(self.max_per_interval), 0), seed)
+            self._initialised = True
+        for r in self._reactions:
+            if r._index is not None:
+                continue
+            kw = {}
+            for which, k in (("type_1", 1), ("type_2", 2)):
+                pp = r._pp.get(which)
+                old = getattr(r, which)
+                if pp is not None and old in pp.changes:
+                    ch = pp.changes[old]
+                    kw["new_type_%d" % k] = int(ch.type)
+                    kw["new_mass_%d" % k] = float(ch.mass)
+                    kw["new_q_%d" % k] = float(ch.q or 0.0)
+            bond_list = -1
+            if not r.is_virtual:
+                if r.fpl.handle is None:
+                    raise RuntimeError("Reaction: the FixedPairList has no interaction (potential) attached")
+                bond_list = r.fpl.handle
+            r._index = e.reaction_add(r.type_1, r.type_2, r.delta_1, r.delta_2, r.min_state_1, r.max_state_1, r.min_state_2,
+                                      r.max_state_2, r.rate, r.cutoff, bond_list=bond_list, min_cutoff=r._cut.min_cutoff,
+                                      intramolecular=r.intramolecular, intraresidual=r.intraresidual, is_virtual=r.is_virtual,
+                                      active=r.active, **kw)
+            r._system = self.system
+
+    def _connect(self, integrator):
+        self._flush()
+        self.system.engine.reactions_enable(True)
+
+    def disconnect(self):
+        self.system.engine.reactions_enable(False)
+
+    def connect(self):
+        self.system.engine.reactions_enable(True)
+
+    def get_timers(self):
+        return []
+
+    def save_reaction_counters(self, filename):
+        ev = self.system.engine.get_events()
+        with open(filename, "w") as f:
+            for r in range(len(self._reactions)):
+                f.write("%d %d\n" % (r, int((ev["reaction"] == r).sum())))
+
+
+class _TopologyManager(object):
+    """integrator.TopologyManager(system): observe_tuple, register_tuple/triplet/quadruplet,
+    initialize_topology (start_simulation.py:211-212,395-440).  The bond graph itself lives in the
+    library (chem_host.hpp); this object only forwards the registrations."""
+
+    def __init__(self, system):
+        self.system = system
+
+    def observe_tuple(self, fpl):
+        pass
+
+    observe_triple = observe_quadruple = observe_tuple
+
+    def register_tuple(self, fpl, t1, t2):
+        pass   # bonds never spawn from other bonds
+
+    def register_triplet(self, ftl, t1, t2, t3):
+        if ftl.handle is None:
+            raise RuntimeError("register_triplet: the FixedTripleList has no interaction attached")
+        self.system.engine.topology_register(ftl.handle, [t1, t2, t3])
+
+    def register_quadruplet(self, fql, t1, t2, t3, t4):
+        if fql.handle is None:
+            raise RuntimeError("register_quadruplet: the FixedQuadrupleList has no interaction attached")
+        self.system.engine.topology_register(fql.handle, [t1, t2, t3, t4])
+
+    def initialize_topology(self):
+        pass
+
+    def _connect(self, integrator):
+        pass
+
+    def get_timers(self):
+        return []
+
+
+class _ExtAnalyze(object):
+    def __init__(self, obj, interval):
+        self.obj, self.interval = obj, max(1, int(interval))
+
+    def perform(self):
+        if hasattr(self.obj, "perform_action"):
+            self.obj.perform_action()
+        elif hasattr(self.obj, "perform"):
+            self.obj.perform()
+
+    def _connect(self, integrator):
+        pass
+
+
+integrator = _ns(
+    VelocityVerlet=_VelocityVerlet, LangevinThermostat=_LangevinThermostat, ChemicalReaction=_ChemicalReaction,
+    Reaction=_Reaction, PostProcessChangeProperty=_PostProcessChangeProperty,
+    TopologyParticleProperties=_TopologyParticleProperties, TopologyManager=_TopologyManager, ExtAnalyze=_ExtAnalyze,
+    StochasticVelocityRescaling=_unsupported("integrator.StochasticVelocityRescaling"),
+    BerendsenThermostat=_unsupported("integrator.BerendsenThermostat"), BerendsenBarostat=_unsupported("integrator.BerendsenBarostat"),
+    Isokinetic=_unsupported("integrator.Isokinetic"), LangevinBarostat=_unsupported("integrator.LangevinBarostat"),
+    CapForce=_unsupported("integrator.CapForce"), RestrictReaction=_unsupported("integrator.RestrictReaction"),
+    DissociationReaction=_unsupported("integrator.DissociationReaction"), ATRPActivator=_unsupported("integrator.ATRPActivator"),
+    ReactionCutoffRandom=_unsupported("integrator.ReactionCutoffRandom"), FixDistances=_unsupported("integrator.FixDistances"),
+    ChangeInRegion=_unsupported("integrator.ChangeInRegion"), BasicDynamicResolution=_unsupported("integrator.BasicDynamicResolution"),
+    PostProcessChangeNeighboursProperty=_unsupported("integrator.PostProcessChangeNeighboursProperty"),
+    PostProcessRemoveNeighbourBond=_unsupported("integrator.PostProcessRemoveNeighbourBond"),
+    PostProcessJoinParticles=_unsupported("integrator.PostProcessJoinParticles"),
+)
+
+
+# ---- analysis ------------------------------------------------------------------------------------
+class _Observable(object):
+    def __init__(self, system, *a):
+        self.system, self.args = system, a
+
+    def compute(self):
+        raise NotImplementedError
+
+
+class _Temperature(_Observable):
+    def compute(self):
+        return self.system.engine.observe()["temperature"]
+
+
+class _KineticEnergy(_Observable):
+    def __init__(self, system, temperature=None):
+        _Observable.__init__(self, system)
+
+    def compute(self):
+        return self.system.engine.observe()["ekin"]
+
+
+class _PotentialEnergy(_Observable):
+    def __init__(self, system, interaction_, compute_method=None):
+        _Observable.__init__(self, system)
+        self.interaction = interaction_
+
+    def compute(self):
+        o = self.system.engine.observe()
+        i = self.interaction
+        if isinstance(i, _VerletListLennardJones):
+            return o["epot_lj"]
+        if isinstance(i, _VerletListTabulated):
+            return o["epot_tab"]
+        h = i.flist.handle
+        return o["epot_list"][h] if h is not None else 0.0
+
+
+class _NPart(_Observable):
+    def compute(self):
+        return self.system.engine.n
+
+
+class _MaxPID(_Observable):
+    def compute(self):
+        return int(self.system.engine.get_state("ID").max())
+
+
+class _NFixedPairListEntries(_Observable):
+    def __init__(self, system, fpl):
+        _Observable.__init__(self, system)
+        self.fpl = fpl
+
+    def compute(self):
+        return self.fpl.totalSize()
+
+
+class _CMVelocity(_Observable):
+    def reset(self):
+        pass   # the synthetic/initial velocities are generated with zero COM momentum
+
+    def compute(self):
+        o = self.system.engine.observe()
+        return Real3D(*o["momentum"])
+
+
+class _ChemicalConversion(_Observable):
+    def __init__(self, system, type_id, total=None):
+        _Observable.__init__(self, system)
+        self.type_id, self.total = type_id, total
+
+    def compute(self):
+        t = self.system.engine.get_state("TYPE")
+        c = float((t == self.type_id).sum())
+        return c / self.total if self.total else c
+
+
+class _ChemicalConversionTypeState(_Observable):
+    def __init__(self, system, type_id, state, total=None):
+        _Observable.__init__(self, system)
+        self.type_id, self.state, self.total = type_id, state, total
+
+    def compute(self):
+        e = self.system.engine
+        c = float(((e.get_state("TYPE") == self.type_id) & (e.get_state("STATE") == self.state)).sum())
+        return c / self.total if self.total else c
+
+
+class _SystemMonitorOutputCSV(object):
+    def __init__(self, filename, delimiter=","):
+        self.filename, self.delimiter = filename, delimiter
+        self._header_written = False
+
+    def write(self, names, row):
+        with open(self.filename, "a") as f:
+            if not self._header_written:
+                f.write(self.delimiter.join(names) + "\n")
+                self._header_written = True
+            f.write(self.delimiter.join("%g" % v for v in row) + "\n")
+
+
+class _SystemMonitor(object):
+    """analysis.SystemMonitor(system, integrator, output) + add_observable/info
+    (start_simulation.py:447-569)."""
+
+    def __init__(self, system, integrator_, output):
+        self.system, self.integrator, self.output = system, integrator_, output
+        self.obs = []
+        self.last = None
+        self.copy_state = None
+
+    def add_observable(self, name, observable, visible=True):
+        self.obs.append((name, observable, visible))
+
+    def perform_action(self):
+        names = ["step", "time"] + [n for n, _, _ in self.obs]
+        row = [self.integrator.step, self.integrator.step * (self.integrator.dt or 0.0)] + [float(o.compute()) for _, o, _ in self.obs]
+        self.last = (names, row)
+        if self.output is not None:
+            self.output.write(names, row)
+
+    def info(self):
+        if self.last is None:
+            return
+        names, row = self.last
+        vis = ["step", "time"] + [n for n, _, v in self.obs if v]
+        print(" ".join("%s=%g" % (n, v) for n, v in zip(names, row) if n in vis))
+
+    def dump(self):
+        pass
+
+
+analysis = _ns(
+    Temperature=_Temperature, KineticEnergy=_KineticEnergy, PotentialEnergy=_PotentialEnergy, NPart=_NPart, MaxPID=_MaxPID,
+    NFixedPairListEntries=_NFixedPairListEntries, CMVelocity=_CMVelocity, ChemicalConversion=_ChemicalConversion,
+    ChemicalConversionTypeState=_ChemicalConversionTypeState, SystemMonitor=_SystemMonitor,
+    SystemMonitorOutputCSV=_SystemMonitorOutputCSV,
+    Pressure=_unsupported("analysis.Pressure"), PressureTensor=_unsupported("analysis.PressureTensor"),
+)
+
+esutil = _ns(RNG=_RNG)
+bc = _ns(OrthorhombicBC=_OrthorhombicBC)
+storage = _ns(DomainDecomposition=_DomainDecomposition)
+
+
+def _gaussian_velocities(T, n, masses, kb=1.0, seed=0):
+    """tools.velocities.gaussian: Maxwell velocities with zero COM momentum (start_simulation.py:136-146)."""
+    rng = np.random.default_rng(seed)
+    m = np.asarray(masses, dtype=np.float64)
+    v = rng.standard_normal((n, 3)) * np.sqrt(kb * T / m)[:, None]
+    v -= (m[:, None] * v).sum(0) / m.sum()
+    return v[:, 0], v[:, 1], v[:, 2]
+
+
+tools = _ns(decomp=_ns(nodeGrid=_node_grid, cellGrid=_cell_grid, tuneSkin=_unsupported("tools.decomp.tuneSkin")),
+            velocities=_ns(gaussian=_gaussian_velocities),
+            analyse=_ns(final_info=lambda *a, **k: None))
+io = _ns(DumpH5MD=_unsupported("io.DumpH5MD"), DumpTopology=_unsupported("io.DumpTopology"), DumpGRO=_unsupported("io.DumpGRO"))

@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""py3 driver with the control flow of ChemLab's start_simulation.py for the in-scope
+configurations: same `@params` CLI, same cadence integers, same timer definition
+(`integratorLoop` = wall seconds inside integrator.run) and the same 4-field benchmark.csv row.
+
+    python -m chemlab_amd.start_simulation @params
+
+Reference: /root/reference/src/start_simulation.py -- cadence :100-103,265-270,645-673; set-up order
+:122-212; thermostat :329-354; main loop :728-796; benchmark row :997-998.  Output files beyond the
+energy CSV, the exclusion list and benchmark.csv (H5MD, topology dumps, .gro) are out of scope (f-3).
+"""
+import math
+import os
+import shutil
+import sys
+import time
+
+from . import espp as espressopp
+from .chemlab import app_args, files_io, gromacs_topology, reaction_parser, reaction_setup
+
+
+def cadence(args, cr_interval=None):
+    """The integers the outer loop runs on (start_simulation.py:100-103,265-270,645-673).
+    Python-2 integer division of `run / integrator_step` is kept."""
+    integrator_step = args.int_step
+    if args.trj_collect > 0:
+        integrator_step = min(args.int_step, args.trj_collect)
+    topol_collect = args.topol_collect
+    if cr_interval:
+        integrator_step = min(cr_interval, integrator_step)
+        topol_collect = min(cr_interval, args.topol_collect)
+    sim_step = args.run // integrator_step
+    has_reaction = bool(cr_interval)
+    k_enable = int(math.ceil(args.start_ar / float(integrator_step))) if (args.start_ar >= 0 and has_reaction) else -1
+    k_stop = int(math.ceil(args.stop_ar / float(integrator_step))) if (args.stop_ar >= 0 and has_reaction) else -1
+    trj_collect = min(args.trj_collect, cr_interval) if cr_interval else args.trj_collect
+    k_trj_collect = int(math.ceil(trj_collect / float(integrator_step)))
+    if args.trj_flush is None:
+        k_trj_flush = 25 if 25 < 10 * k_trj_collect else 10 * k_trj_collect
+    else:
+        k_trj_flush = int(math.ceil(args.trj_flush / float(integrator_step)))
+    energy_collect = min(cr_interval, args.energy_collect) if cr_interval else args.energy_collect
+    return dict(integrator_step=integrator_step, sim_step=sim_step, k_enable_reactions=k_enable, k_stop_reactions=k_stop,
+                k_trj_collect=k_trj_collect, k_trj_flush=k_trj_flush, topol_collect=topol_collect, energy_collect=energy_collect)
+
+
+def main(argv=None, hooks=None, quiet=False):
+    log = (lambda *a: None) if quiet else print
+    parser = app_args._args()
+    args = parser.parse_args(argv)
+    parser.save_to_file("%sparams.out" % args.output_prefix, args)
+    if args.pressure is not None:
+        raise NotImplementedError("barostats are outside the MI355X hot-path scope")
+    if args.coulomb_cutoff > 0:
+        log("note: coulomb_cutoff=%g ignored -- truncated Coulomb is outside the hot-path scope" % args.coulomb_cutoff)
+    kb, mass_factor = args.kb, args.mass_factor
+    lj_cutoff, cg_cutoff = args.lj_cutoff, args.cg_cutoff
+    max_cutoff = max(lj_cutoff, cg_cutoff)            # ignores coulomb_cutoff
+    gt = gromacs_topology.GromacsTopology(args.top).read()
+    conf = files_io.GROFile(args.conf).read()
+    box = conf.box
+    cad = cadence(args)
+    skin = 0.16 if args.skin == "auto" else float(args.skin)
+    rng_seed = args.rng_seed
+    props, plist = gromacs_topology.gen_particle_list(conf, gt, espressopp)
+    for p in plist:
+        p[3] *= mass_factor
+    log("Reads %d particles" % len(plist))
+    if args.gen_velocity:
+        vx, vy, vz = espressopp.tools.velocities.gaussian(args.temperature, len(plist), [p[3] for p in plist], kb=kb, seed=rng_seed)
+        props.append("v")
+        for i, p in enumerate(plist):
+            p.append(espressopp.Real3D(vx[i], vy[i], vz[i]))
+    system = espressopp.System()
+    system.rng = espressopp.esutil.RNG(rng_seed)
+    system.skin = skin
+    node_grid = [int(x) for x in args.node_grid.split(",")] if args.node_grid else espressopp.tools.decomp.nodeGrid(1)
+    cell_grid = espressopp.tools.decomp.cellGrid(box, node_grid, max_cutoff, skin)
+    log("Cell grid: (%d, %d, %d)" % tuple(int(c) for c in cell_grid))
+    system.bc = espressopp.bc.OrthorhombicBC(system.rng, box)
+    system.storage = espressopp.storage.DomainDecomposition(system, node_grid, cell_grid)
+    integrator = espressopp.integrator.VelocityVerlet(system)
+    integrator.dt = args.dt
+    system.integrator = integrator
+    system.storage.addParticles(plist, *props)
+    system.storage.decompose()
+    if args.exclusion_list and os.path.exists(args.exclusion_list):
+        gt.exclusions = set(files_io.read_exclusion_list(args.exclusion_list))
+    if gt.exclusions:
+        files_io.write_exclusion_list("exclusion_%s.list" % os.path.basename(args.top).split(".")[0], gt.exclusions)
+    dynamic_exclusion_list = espressopp.DynamicExcludeList(integrator, sorted(gt.exclusions))
+    log("Excluded pairs from LJ interaction: %d" % len(gt.exclusions))
+    verletlist = espressopp.VerletList(system, cutoff=max_cutoff, exclusionlist=dynamic_exclusion_list)
+    log("Bonds: %d\nAngles: %d\nDihedrals: %d" % (len(gt.bonds), len(gt.angles), len(gt.dihedrals)))
+    topology_manager = espressopp.integrator.TopologyManager(system)
+    system.topology_manager = topology_manager
+    hooks = hooks or {}
+    ar, chem_fpls, cr_interval, dynamic_types = None, [], None, set()
+    if args.reactions is not None and os.path.exists(args.reactions):
+        rc = reaction_parser.parse_config(args.reactions)
+        sc = reaction_setup.SetupReactions(espressopp, system, verletlist, gt, topology_manager, rc, args)
+        ar, chem_fpls = sc.setup_reactions()
+        dynamic_types = sc.dynamic_types
+        shutil.copyfile(args.reactions, "%s_%s_%s" % (args.output_prefix, rng_seed, os.path.basename(args.reactions)))
+        cr_interval = rc["general"]["interval"]
+        cad = cadence(args, cr_interval)
+        log("Change integrator step to %d" % cad["integrator_step"])
+    table_groups = args.table_groups.split(",") if args.table_groups else []
+    gromacs_topology.set_nonbonded_interactions(espressopp, system, gt, verletlist, lj_cutoff, tab_cutoff=cg_cutoff, tables_=table_groups,
+                                                table_dir=os.path.dirname(os.path.abspath(args.top)))
+    bonded = gromacs_topology.set_bonded_interactions(espressopp, system, gt, dynamic_types)
+    angles = gromacs_topology.set_angle_interactions(espressopp, system, gt, dynamic_types)
+    if gt.dihedrals:
+        raise NotImplementedError("[ dihedrals ] from topology files: lowest priority in SURVEY.md 8 (a8); use the C ABI directly")
+    # thermostat (start_simulation.py:329-354)
+    temperature = args.temperature * kb
+    if args.thermostat == "lv":
+        th = espressopp.integrator.LangevinThermostat(system)
+        th.temperature, th.gamma = temperature, args.thermostat_gamma
+        integrator.addExtension(th)
+    elif args.thermostat != "no":
+        raise NotImplementedError("thermostat '%s' is outside the hot-path scope (Langevin 'lv' or 'no')" % args.thermostat)
+    # topology manager wiring (start_simulation.py:378-441): spawned angles land in the dynamic Types list
+    for name, (fl, inter) in list(bonded.items()):
+        dynamic_exclusion_list.observe_tuple(fl)
+        topology_manager.observe_tuple(fl)
+    for _, fpl, _ in chem_fpls:
+        dynamic_exclusion_list.observe_tuple(fpl)
+        topology_manager.observe_tuple(fpl)
+    if "angle_dynamic" in angles:
+        ftl, inter = angles["angle_dynamic"]
+        dynamic_exclusion_list.observe_triple(ftl)
+        for types_ in inter._typed:
+            topology_manager.register_triplet(ftl, *types_)
+    topology_manager.initialize_topology()
+    integrator.addExtension(topology_manager)
+    # observables (start_simulation.py:447-569)
+    energy_file = "%s_energy_%s.csv" % (args.output_prefix, rng_seed)
+    mon = espressopp.analysis.SystemMonitor(system, integrator, espressopp.analysis.SystemMonitorOutputCSV(energy_file))
+    mon.add_observable("T", espressopp.analysis.Temperature(system))
+    mon.add_observable("Ekin", espressopp.analysis.KineticEnergy(system))
+    for k in range(system.getNumberOfInteractions()):
+        mon.add_observable(system.getNameOfInteraction(k), espressopp.analysis.PotentialEnergy(system, system.getInteraction(k)), False)
+    for i, (gname, fpl, _) in enumerate(chem_fpls):
+        mon.add_observable("count_%d" % i, espressopp.analysis.NFixedPairListEntries(system, fpl))
+    integrator.addExtension(espressopp.integrator.ExtAnalyze(mon, cad["energy_collect"]))
+    espressopp.analysis.CMVelocity(system).reset()
+    # main loop (start_simulation.py:728-796)
+    reactions_enabled = False
+    total_time = time.time()
+    integrator_loop = 0.0
+    if "hook_before_sim" in hooks:
+        hooks["hook_before_sim"](system, integrator, ar, gt)
+    for k in range(cad["sim_step"]):
+        mon.info() if not quiet else None
+        if cad["k_enable_reactions"] == k and ar is not None:
+            log("Enabling chemical reactions")
+            integrator.addExtension(ar)
+            reactions_enabled = True
+            if "hook_init_reaction" in hooks and not hooks["hook_init_reaction"](system, integrator, ar, gt, args):
+                raise RuntimeError("hook_init_reaction return False")
+        if reactions_enabled and cad["k_stop_reactions"] == k:
+            ar.disconnect()
+        t0 = time.time()
+        integrator.run(cad["integrator_step"])
+        integrator_loop += time.time() - t0
+        if "hook_at_step" in hooks:
+            hooks["hook_at_step"](system, integrator, ar, gt, args, k * cad["integrator_step"])
+    total_time = time.time() - total_time
+    npart = espressopp.analysis.NPart(system).compute()
+    with open("%s_%s_benchmark.csv" % (args.output_prefix, rng_seed), "a+") as f:
+        f.write("%d %d %s %s\n" % (1, npart, total_time, integrator_loop))
+    log("finished: %d steps, integratorLoop %.3f s, %.1f steps/s" % (cad["sim_step"] * cad["integrator_step"], integrator_loop,
+                                                                       cad["sim_step"] * cad["integrator_step"] / max(integrator_loop, 1e-12)))
+    return dict(system=system, integrator=integrator, gt=gt, ar=ar, chem_fpls=chem_fpls, cadence=cad, args=args,
+                total_time=total_time, integrator_loop=integrator_loop, bonded=bonded, angles=angles, monitor=mon)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
