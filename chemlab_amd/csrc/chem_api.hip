@@ -134,6 +134,8 @@ template <typename R> struct CtxT : Ctx {
   DBuf<Candidate> cand_loc; DBuf<int> cnt_all;   // reaction candidates before the all-gather
   int acap() const { return dd_on ? cap : n; }
   int64_t dd_rebuilds = 0;
+  int* hflag = nullptr; int* hflag_dev = nullptr; int hticket = 0;   // pinned decision word + ticket
+  DBuf<double> dd_vals;
   int S = 0;
   bool use_tiles = false, want32 = false;   // int32 list only built on demand (reaction steps, diagnostics)
   ActMask act{}; UniLJ uni{}; bool uniform_lj = false;
@@ -156,8 +158,11 @@ template <typename R> struct CtxT : Ctx {
 
   CtxT() { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
   ~CtxT() override {
+    if (stream) (void)hipStreamSynchronize(stream);   // nothing may still write the pinned words or the buffers
+    tr.reset();
     for (auto e : ev) (void)hipEventDestroy(e);
     if (pin_ev) (void)hipHostFree(pin_ev);
+    if (hflag) (void)hipHostFree(hflag);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void sync() override { HIPCHK(hipStreamSynchronize(stream)); }
@@ -446,7 +451,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void decide_and_rebuild() {
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin, opt_criterion, 3);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
     launch_rebuild_chain();
   }
 
@@ -638,12 +643,33 @@ template <typename R> struct CtxT : Ctx {
   // position update (posted before the decision is known: it is needed unless we rebuild), and the
   // collective rebuild when the trigger fired.  One host synchronisation per step.
   void dd_step_sync() {
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), 256), 0.5 * skin, opt_criterion, 1);
-    tr->allreduce_max_f64(&ctl.p->step_m2, 1, stream);
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, 0, 0.5 * skin, opt_criterion, 2);
-    halo_update();
-    DevCtl h = read_ctl();
-    if (h.need_rebuild) rebuild_dd();
+    if (!hflag) {
+      HIPCHK(hipHostMalloc((void**)&hflag, 4096, hipHostMallocMapped | hipHostMallocCoherent));
+      hflag[0] = hflag[1] = 0;
+      HIPCHK(hipHostGetDevicePointer((void**)&hflag_dev, hflag, 0));
+      dd_vals.alloc(64);
+    }
+    // local fold -> ctl->step_m2; its all-to-all rides in the halo exchange group; decision from the
+    // P gathered values, mirrored into pinned host memory so that the host learns it by polling one
+    // word (no memcpy, no stream synchronisation call)
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), 256), 0.5 * skin, opt_criterion, 1,
+                       (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+    tr->exchange_with_scalar(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
+                             x4.p + G - nglo, nglo * sizeof(V4), lower, upper, &ctl.p->step_m2, dd_vals.p, stream);
+    const int ticket = ++hticket;
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, 0, 0.5 * skin, opt_criterion, 2,
+                       dd_vals.p, P, (volatile int*)hflag_dev, ticket);
+    if (getenv("CHEM_DD_NOPOLL")) { DevCtl hc = read_ctl(); if (hc.need_rebuild) rebuild_dd(); return; }
+    volatile int* hf = hflag;
+    long long spins = 0;
+    while (hf[1] != ticket) {
+      if ((++spins & 0xfffff) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {   // stream drained or failed: re-check once, then give up
+        if (hf[1] == ticket) break;
+        HIPCHK(hipStreamSynchronize(stream));
+        if (hf[1] != ticket) throw ChemError(CHEM_EDEVICE, "rebuild decision never arrived from the device");
+      }
+    }
+    if (hf[0]) rebuild_dd();
   }
 
   // ---- the hot call -------------------------------------------------------------------

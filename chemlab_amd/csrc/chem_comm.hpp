@@ -32,6 +32,11 @@ struct Transport {
   // Byte counts; all four may differ.  Enqueued on `s`.
   virtual void exchange(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
                         void* from_lo, size_t from_lo_bytes, int lower, int upper, hipStream_t s) = 0;
+  // The same exchange plus, in the same communication phase, every rank's `my` value delivered to
+  // slot [rank] of every other rank's `all` array (the step's displacement maximum: the list-rebuild
+  // decision needs the global max, and a separate all-reduce would cost a second launch + latency).
+  virtual void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
+                                    void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) = 0;
   virtual void allreduce_max_f64(double* dev, size_t count, hipStream_t s) = 0;
   virtual void allreduce_sum_f64(double* dev, size_t count, hipStream_t s) = 0;
   // out must hold nranks*bytes; in may alias out + rank*bytes
@@ -45,6 +50,11 @@ struct SelfTransport : Transport {
     if (dn_bytes != from_up_bytes || up_bytes != from_lo_bytes) throw ChemError(CHEM_ECOMM, "self transport: size mismatch");
     if (dn_bytes && hipMemcpyAsync(from_up, dn, dn_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) throw ChemError(CHEM_ECOMM, "self copy");
     if (up_bytes && hipMemcpyAsync(from_lo, up, up_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) throw ChemError(CHEM_ECOMM, "self copy");
+  }
+  void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
+                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) override {
+    exchange(dn, dn_bytes, up, up_bytes, from_up, from_up_bytes, from_lo, from_lo_bytes, lower, upper, s);
+    (void)hipMemcpyAsync(all, my, sizeof(double), hipMemcpyDeviceToDevice, s);
   }
   void allreduce_max_f64(double*, size_t, hipStream_t) override {}
   void allreduce_sum_f64(double*, size_t, hipStream_t) override {}
@@ -114,6 +124,20 @@ struct RcclTransport : Transport {
     ck(a.Recv(from_lo, from_lo_bytes, RcclApi::kInt8, lower, comm, s), "ncclRecv");
     ck(a.GroupEnd(), "ncclGroupEnd");
   }
+  void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
+                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) override {
+    RcclApi& a = rccl_api();
+    ck(a.GroupStart(), "ncclGroupStart");
+    ck(a.Send(dn, dn_bytes, RcclApi::kInt8, lower, comm, s), "ncclSend");
+    ck(a.Send(up, up_bytes, RcclApi::kInt8, upper, comm, s), "ncclSend");
+    ck(a.Recv(from_up, from_up_bytes, RcclApi::kInt8, upper, comm, s), "ncclRecv");
+    ck(a.Recv(from_lo, from_lo_bytes, RcclApi::kInt8, lower, comm, s), "ncclRecv");
+    for (int r = 0; r < nranks; ++r) {   // 8-byte all-to-all riding in the same group (one launch, one latency)
+      ck(a.Send(my, sizeof(double), RcclApi::kInt8, r, comm, s), "ncclSend");
+      ck(a.Recv(all + r, sizeof(double), RcclApi::kInt8, r, comm, s), "ncclRecv");
+    }
+    ck(a.GroupEnd(), "ncclGroupEnd");
+  }
   void allreduce_max_f64(double* dev, size_t count, hipStream_t s) override {
     ck(rccl_api().AllReduce(dev, dev, count, RcclApi::kFloat64, RcclApi::kMax, comm, s), "ncclAllReduce");
   }
@@ -169,6 +193,11 @@ struct LocalTransport : Transport {
     if (from_lo_bytes) ck(hipMemcpyAsync(from_lo, pl.b, from_lo_bytes, hipMemcpyDeviceToDevice, s));
     ck(hipStreamSynchronize(s));
     hub->barrier();
+  }
+  void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
+                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) override {
+    exchange(dn, dn_bytes, up, up_bytes, from_up, from_up_bytes, from_lo, from_lo_bytes, lower, upper, s);
+    allgather(my, all, sizeof(double), s);
   }
   void allreduce(double* dev, size_t count, hipStream_t s, bool is_max) {
     std::vector<double> v(count);

@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
 // phase 3: both (single GPU); phase 1: fold only -> ctl->step_m2 (then max over ranks);
 // phase 2: decide from ctl->step_m2.
 template <typename R>
-__global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned long long* __restrict__ blockmax, int nblk, double half_skin, int criterion, int phase) {
+__global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned long long* __restrict__ blockmax, int nblk, double half_skin, int criterion, int phase,
+                                                         const double* __restrict__ gathered, int ngathered, volatile int* __restrict__ host_flag, int ticket) {
   unsigned long long m = 0;
   if (phase & 1) {
     for (int k = threadIdx.x; k < nblk; k += 1024) { unsigned long long b = blockmax[k]; blockmax[k] = 0ull; m = b > m ? b : m; }
@@ -172,13 +173,19 @@ __global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned l
       for (int k = 1; k < 16; ++k) m = wm[k] > m ? wm[k] : m;
       m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
       ctl->step_m2 = m2;
-    } else m2 = ctl->step_m2;
+    } else if (gathered) { m2 = gathered[0]; for (int q = 1; q < ngathered; ++q) m2 = gathered[q] > m2 ? gathered[q] : m2; }
+    else m2 = ctl->step_m2;
     if (phase & 2) {
       double acc = criterion ? sqrt(m2) : ctl->acc_maxdist + sqrt(m2);
       const int need = (acc > half_skin) || ctl->force_rebuild;
       if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
       ctl->acc_maxdist = acc;
       ctl->need_rebuild = need;
+      if (host_flag) {   // pinned, host-visible: [0] decision, [1] ticket (written last); the host spins on the ticket
+        host_flag[0] = need;
+        __threadfence_system();
+        host_flag[1] = ticket;
+      }
     }
   }
 }

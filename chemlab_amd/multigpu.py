@@ -49,6 +49,9 @@ def init_process_group():
     import torch.distributed as dist
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")            # plain `python bench.py` = a world of one
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="gloo")
     return dist
 
