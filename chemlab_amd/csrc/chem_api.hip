@@ -111,7 +111,7 @@ template <typename R> struct CtxT : Ctx {
   bool lj_only = true;
   bool state_mirror_stale = false;   // top.state lags the device after reaction steps
   int tile_cap = 0;       // LDS slots of one staged tile (dynamic LDS)
-  size_t tile_lds_bytes() const { return (size_t)(tile_cap + 2) * sizeof(V4) + 16; }
+  size_t tile_lds_bytes() const { return (size_t)(tile_cap + 5) * sizeof(V4) + 16; }
   hipStream_t stream = nullptr;
   int n = 0;
   DBuf<V4> x4, v4, f4, x4o, v4o, tab, x0;
@@ -429,7 +429,7 @@ template <typename R> struct CtxT : Ctx {
     if (use_tiles) {
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c);
       hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
-      hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(std::min((ntiles + 7) / 8 * 8, 1024)), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
+      hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
                          excl_start.p, excl_list.p, has_excl, act, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
     } else if (box.nc[0] > 0)
       hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,

@@ -753,13 +753,33 @@ __device__ __forceinline__ void tile_load_desc(TileLDS<R>& T, const TileLDS<R>* 
 // kernel), 1: .w = (global index << 4 | type) (list build).  Caller synchronises afterwards.
 // All global loads of a wave are issued before the first LDS write so that the staging costs one
 // memory latency, not one per row chunk.
-template <typename R, int BS>
+template <typename R, int BS, bool LEAN = false>
 __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx, const int CAP,
                                           const Vec4<R>* __restrict__ x4, int wmode) {
   constexpr int NW = BS / 64, RPW = (NROW + NW - 1) / NW;
   const int t = threadIdx.x;
   const int w = t >> 6, l = t & 63;
   if (t == 0) sx[T.geom[3]] = mk4<R>((R)1e18, (R)1e18, (R)1e18, (R)0);
+  if constexpr (LEAN) {
+    // register-lean variant (list build: staging is <2 % of the tile's time, occupancy matters more)
+    for (int r = w; r < NROW; r += NW) {
+      const int len = T.celloff[r][SX], o0 = T.rowoff[r];
+      for (int e = l; e < len; e += 64) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < SX; ++q) k += (e >= T.celloff[r][q]) ? 1 : 0;
+        const int g = T.cellg[r][k] + (e - T.celloff[r][k]);
+        const int dst = o0 + e;
+        if (dst < CAP) {
+          Vec4<R> p = x4[g];
+          p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
+          if (wmode) p.w = idx_as_real((g << 4) | (int)p.w, (R)0);
+          sx[dst] = p;
+        }
+      }
+    }
+    return;
+  }
   Vec4<R> pv[RPW][2];
   int pk_[RPW][2], pg[RPW][2];
 #pragma unroll
@@ -862,7 +882,7 @@ __global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const V
     __syncthreads();
     tile_load_desc<R>(T, desc, tile);
     __syncthreads();
-    tile_fill<R, BS>(T, sx, CAP, x4, 1);
+    tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
     __syncthreads();
     const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4], hbase = T.geom[5];
     unsigned short* reg16 = nl16 + (size_t)hbase * S16;
@@ -912,11 +932,46 @@ __global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const V
       //  2. the few hits (~15 %) are peeled off the mask one by one for the type / exclusion /
       //     activity filters and the chunked store.
       // The branchy hit handling no longer sits in the loop that runs 475 times per particle.
-      for (int dz = 0; dz < 3; ++dz) for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll 1
+      for (int dzy = 0; dzy < 9; ++dzy) {
+        const int dz = dzy / 3, dy = dzy - 3 * dz;
         const int r = (lz + dz) * SY + (ly + dy);
         const int a = T.rowoff[r] + T.celloff[r][lx];
         int b = T.rowoff[r] + T.celloff[r][lx + 3];
         b = b < total ? b : total;
+        if constexpr (sizeof(R) == 4) {
+          // fp32 fast path: 32-candidate segments, one 32-bit shift-register mask per lane.  Each test
+          // is ds_read_b128 + 3 sub + mul + 2 fma + v_cmp + v_addc (carry shifts the result in);
+          // reads run up to 3 slots past the run (the LDS image has 4 slack slots), the surplus
+          // bits are masked off afterwards instead of selecting a dummy address per candidate.
+          typedef float f32x4 __attribute__((ext_vector_type(4)));
+          for (int s0 = a; s0 < b; s0 += 32) {
+            const int len = (b - s0) < 32 ? (b - s0) : 32;
+            const int ng = (len + 3) >> 2;
+            unsigned int m = 0;
+            typedef __attribute__((address_space(3))) const volatile f32x4 lds_f32x4;
+            lds_f32x4* base = (lds_f32x4*)(sx) + s0;     // volatile: keeps the 16-byte read (b128 costs half the LDS cycles of b96)
+            for (int g = 0; g < ng; ++g) {
+              f32x4 xj[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) xj[u] = base[4 * g + u];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float dx = xi.x - xj[u].x, dy_ = xi.y - xj[u].y, dz_ = xi.z - xj[u].z;
+                const float r2 = dx * dx + dy_ * dy_ + dz_ * dz_;
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r2), "v"(rl2) : "vcc");
+              }
+            }
+            m <<= 32 - 4 * ng;                                     // candidate u -> bit 31-u
+            m &= ~(len < 32 ? (0xffffffffu >> len) : 0u);
+            while (m) {
+              const int k = __clz((int)m);
+              m &= ~(0x80000000u >> k);
+              const int sl = s0 + k;
+              hit(sl, real_as_idx(sx[sl].w));
+            }
+          }
+        } else {
         for (int s0 = a; s0 < b; s0 += 64) {
           const int len = (b - s0) < 64 ? (b - s0) : 64;
           unsigned int mlo = 0, mhi = 0;
@@ -940,6 +995,7 @@ __global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const V
             const int s = s0 + k;
             hit(s, real_as_idx(sx[s].w));
           }
+        }
         }
       }
       // pad the last chunk with the far-away dummy slot (chunks are read whole)
