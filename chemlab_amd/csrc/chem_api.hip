@@ -138,7 +138,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<double> dd_vals;
   int S = 0;
   bool use_tiles = false, want32 = false;   // int32 list only built on demand (reaction steps, diagnostics)
-  ActMask act{}; UniLJ uni{}; bool uniform_lj = false;
+  ActMask act{}; UniLJ uni{}; bool uniform_lj = false; bool all_active = false;
   int ntiles = 0;
   DBuf<int> excl_start, excl_list; int has_excl = 0;
   DBuf<int> bstart; DBuf<BondedEntry> bent; DBuf<BondedParam> bpar; int64_t nbent = 0;
@@ -370,6 +370,8 @@ template <typename R> struct CtxT : Ctx {
       }
     }
     if (!opt_skip_inactive || !first) uniform_lj = false;
+    all_active = true;   // every pair of types in use carries a potential: the list build skips the per-hit type filter
+    for (int a = 0; a < nt; ++a) for (int b = 0; b < nt; ++b) if (!((act.row[a] >> b) & 1u)) all_active = false;
     if (uniform_lj) {
       const double s6 = std::pow(first->sig, 6), s12 = s6 * s6;
       uni.drc2 = first->rc * first->rc; uni.dlj1 = 48.0 * first->eps * s12; uni.dlj2 = 24.0 * first->eps * s6;
@@ -430,7 +432,7 @@ template <typename R> struct CtxT : Ctx {
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c);
       hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
       hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
-                         excl_start.p, excl_list.p, has_excl, act, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
+                         excl_start.p, excl_list.p, has_excl, act, all_active ? 1 : 0, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
     } else if (box.nc[0] > 0)
       hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
                          excl_start.p, excl_list.p, has_excl, nlist.p, nn.p, S, c);

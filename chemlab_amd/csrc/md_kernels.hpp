@@ -750,7 +750,7 @@ __device__ __forceinline__ void tile_load_desc(TileLDS<R>& T, const TileLDS<R>* 
 }
 
 // stages the stencil of the tile described by T into sx.  wmode 0: .w = particle type (force
-// kernel), 1: .w = (global index << 4 | type) (list build).  Caller synchronises afterwards.
+// kernel), 1: .w = (global index << 5 | type) (list build; bit 4 stays clear so that v_bfe can take .w as its offset).  Caller synchronises afterwards.
 // All global loads of a wave are issued before the first LDS write so that the staging costs one
 // memory latency, not one per row chunk.
 template <typename R, int BS, bool LEAN = false>
@@ -773,7 +773,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
         if (dst < CAP) {
           Vec4<R> p = x4[g];
           p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
-          if (wmode) p.w = idx_as_real((g << 4) | (int)p.w, (R)0);
+          if (wmode) p.w = idx_as_real((g << 5) | (int)p.w, (R)0);
           sx[dst] = p;
         }
       }
@@ -811,7 +811,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
         if (dst < CAP) {
           Vec4<R> p = pv[rr][c];
           p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
-          if (wmode) p.w = idx_as_real((pg[rr][c] << 4) | (int)p.w, (R)0);
+          if (wmode) p.w = idx_as_real((pg[rr][c] << 5) | (int)p.w, (R)0);
           sx[dst] = p;
         }
       }
@@ -829,7 +829,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
       if (dst < CAP) {
         Vec4<R> p = x4[g];
         p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
-        if (wmode) p.w = idx_as_real((g << 4) | (int)p.w, (R)0);
+        if (wmode) p.w = idx_as_real((g << 5) | (int)p.w, (R)0);
         sx[dst] = p;
       }
     }
@@ -869,10 +869,10 @@ __device__ __forceinline__ int ntiles_of(const int nc[3]) {
 struct ActMask { unsigned int row[kMaxTypes]; };   // bit tj of row[ti]: pair (ti,tj) has a potential
 
 template <typename R, int BS>
-__global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+__global__ __launch_bounds__(BS, 6) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
                                                     const TileLDS<R>* __restrict__ desc, R rl2,
                                                     const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
-                                                    ActMask act, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
+                                                    ActMask act, int all_active, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
                                                     int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
   __shared__ TileLDS<R> T;
@@ -897,12 +897,14 @@ __global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const V
       const int eh = inrun + T.celloff[hr][1];
       int lx = 0;
       for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
-      const Vec4<R> xi = sx[T.rowoff[hr] + eh];
+      const int sself = T.rowoff[hr] + eh;
+      const Vec4<R> xi = sx[sself];
       const unsigned int arow = act.row[real_as_idx(xi.w) & 15];
       int e0 = 0, e1 = 0;
       if (has_excl) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
       int cnt = 0, cnt16 = 0;
       int* row32 = nlist ? nlist + (size_t)p * S : nullptr;
+      const bool plain = e1 == e0 && !row32;
       uint4* regq = reinterpret_cast<uint4*>(reg16) + q;   // chunk c of this particle: regq[c * nhome]
       // accepted slots are shifted into a 128-bit register; every 8th append stores one whole
       // 16-byte chunk (instead of eight scattered 2-byte stores)
@@ -916,7 +918,7 @@ __global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const V
         ++cnt16;
       };
       auto hit = [&](int s, int jw) {
-        const int j = jw >> 4;
+        const int j = jw >> 5;
         bool ok = j != p;
         if (ok && e1 > e0) {
           const int tgj = tag[j];
@@ -948,7 +950,7 @@ __global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const V
           for (int s0 = a; s0 < b; s0 += 32) {
             const int len = (b - s0) < 32 ? (b - s0) : 32;
             const int ng = (len + 3) >> 2;
-            unsigned int m = 0;
+            unsigned int m = 0, ma = 0;
             typedef __attribute__((address_space(3))) const volatile f32x4 lds_f32x4;
             lds_f32x4* base = (lds_f32x4*)(sx) + s0;     // volatile: keeps the 16-byte read (b128 costs half the LDS cycles of b96)
             for (int g = 0; g < ng; ++g) {
@@ -960,15 +962,30 @@ __global__ __launch_bounds__(BS) void k_nlist_tiles(int ntiles, int CAP, const V
                 const float dx = xi.x - xj[u].x, dy_ = xi.y - xj[u].y, dz_ = xi.z - xj[u].z;
                 const float r2 = dx * dx + dy_ * dy_ + dz_ * dz_;
                 asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r2), "v"(rl2) : "vcc");
+                ma = (ma << 1) | __builtin_amdgcn_ubfe(arow, __float_as_uint(xj[u].w), 1u);   // type pair carries a potential
               }
             }
             m <<= 32 - 4 * ng;                                     // candidate u -> bit 31-u
             m &= ~(len < 32 ? (0xffffffffu >> len) : 0u);
-            while (m) {
-              const int k = __clz((int)m);
-              m &= ~(0x80000000u >> k);
-              const int sl = s0 + k;
-              hit(sl, real_as_idx(sx[sl].w));
+            if (plain) {
+              // no exclusions and no int32 row for this particle: the type filter was folded into the
+              // test loop (ma) and the self pair is cleared from the mask, so a hit needs nothing from
+              // memory and the peel loop has no LDS latency in it
+              m &= ma << (32 - 4 * ng);
+              const unsigned int ks = (unsigned int)(sself - s0);
+              if (ks < 32u) m &= ~(0x80000000u >> ks);
+              while (m) {
+                const int k = __clz((int)m);
+                m &= ~(0x80000000u >> k);
+                push((unsigned int)(s0 + k));
+              }
+            } else {
+              while (m) {
+                const int k = __clz((int)m);
+                m &= ~(0x80000000u >> k);
+                const int sl = s0 + k;
+                hit(sl, real_as_idx(sx[sl].w));
+              }
             }
           }
         } else {
