@@ -85,6 +85,7 @@ struct Ctx {
   int opt_time_pair = 0;    // HIP-event timing of every pair-force launch
   int opt_fuse = 1;         // fused integrate2+integrate1
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
+  int opt_fused = 1;        // rebuild chain as one persistent launch with grid barriers (single domain, tiles)
   int opt_criterion = 0;     // 1: rebuild when max |x - x(last build)| > skin/2 ; 0: reference's accumulated per-step maxima
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
@@ -118,6 +119,9 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> tag, tago, rtag, state, res_id, mol_id;
   DBuf<int4> img4, img4o;
   DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
+  // fused rebuild (single domain, tiles): segment scans + grid barrier state
+  DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot; DBuf<GridBar> gbar;
+  int fused_grid = 0, fused_par = 0, seg_shift = 0, tseg_shift = 0; bool use_fused = false;
   DBuf<int> nlist, nn, nnh;
   DBuf<unsigned short> nl16;
   DBuf<TileLDS<R>> tdesc;
@@ -218,8 +222,44 @@ template <typename R> struct CtxT : Ctx {
     }
     ntiles = use_tiles ? ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY) * (((dd_on ? ncz : box.nc[2]) + HZ - 1) / HZ) : 0;
     alloc_lists();
+    setup_fused();
     HIPCHK(hipStreamSynchronize(stream));
     geom_dirty = false; resort = true;
+  }
+
+  // Fused rebuild kernel: the grid must be co-resident (grid barriers), so it is sized from the
+  // occupancy of the kernel itself on this device.
+  void setup_fused() {
+    use_fused = false;
+    if (!opt_fused || !use_tiles || dd_on) return;
+    const void* fn = reinterpret_cast<const void*>(&k_rebuild_fused<R, 512>);
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes()));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, tile_lds_bytes()) != hipSuccess || per_cu < 1) return;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    int g = std::min(per_cu * prop.multiProcessorCount, 1024) / 8 * 8;
+    if (g < 8) return;
+    fused_grid = g;
+    auto shift_for = [&](int nitem) { int sh = 0; while (((nitem + (1 << sh) - 1) >> sh) > g) ++sh; return sh; };
+    seg_shift = shift_for(box.ncell); tseg_shift = shift_for(ntiles);
+    cell_loc.alloc(box.ncell + 1); seg_tot.alloc(1024); tile_n.alloc(ntiles + 1); tile_loc.alloc(ntiles + 1); tseg_tot.alloc(1024);
+    if (!gbar.p) { gbar.alloc(1); HIPCHK(hipMemsetAsync(gbar.p, 0, sizeof(GridBar), stream)); }
+    use_fused = true;
+  }
+  void launch_rebuild_fused() {
+    FusedArgs<R> a{};
+    a.n = n; a.ncell = box.ncell; a.ntiles = ntiles; a.CAP = tile_cap; a.S = S; a.has_excl = has_excl; a.criterion = opt_criterion;
+    a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = cdiv(n, 256); a.want32 = want32 ? 1 : 0;
+    a.half_skin = 0.5 * skin; a.rl2 = (R)((rc + skin) * (rc + skin));
+    a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
+    a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
+    a.cell_cnt = cell_cnt.p; a.cell_of = cell_of.p; a.slot_of = slot_of.p; a.cell_start = cell_start.p; a.cell_loc = cell_loc.p;
+    a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
+    a.desc = tdesc.p; a.excl_start = excl_start.p; a.excl_list = excl_list.p; a.nl16 = nl16.p; a.nnh = nnh.p; a.nlist = nlist.p; a.nn = nn.p;
+    a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
+    hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), tile_lds_bytes(), stream, a);
+    fused_par ^= 1;
   }
 
   void set_tile_lds_attr() {
@@ -453,6 +493,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void decide_and_rebuild() {
+    if (use_fused) { launch_rebuild_fused(); return; }
     hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
     launch_rebuild_chain();
   }
@@ -548,6 +589,7 @@ template <typename R> struct CtxT : Ctx {
       DevCtl h = read_ctl();
       if (dd_on) agree_flags(h);
       if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
+      if (h.barrier_timeout) throw ChemError(CHEM_ESTATE, "fused rebuild: grid barrier timed out (device shared with another job?); set option fused_rebuild=0");
       if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil holds " + std::to_string(h.stage_overflow) + " particles, LDS tile capacity " + std::to_string(use_tiles ? tile_cap : 1536) + " (density fluctuation beyond the 12 % margin)");
       if (!h.nl_overflow) { resort = false; tm.rebuild_wall_s += now_s() - t0; return; }
       int newS = ((int)(h.nl_overflow * 1.25) + 31) / 16 * 16;
@@ -631,6 +673,11 @@ template <typename R> struct CtxT : Ctx {
 
   void check_flags() {
     DevCtl h = read_ctl();
+    if (use_fused && getenv("CHEM_FUSED_STAMPS")) {   // phase boundaries of the last rebuild, 100 MHz ticks
+      GridBar g; HIPCHK(hipMemcpy(&g, gbar.p, sizeof(GridBar), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[fused] bin %.1f scan %.1f place %.1f sort %.1f desc %.1f list %.1f us\n", (g.stamp[1] - g.stamp[0]) * 0.01, (g.stamp[2] - g.stamp[1]) * 0.01,
+              (g.stamp[3] - g.stamp[2]) * 0.01, (g.stamp[4] - g.stamp[3]) * 0.01, (g.stamp[5] - g.stamp[4]) * 0.01, (g.stamp[6] - g.stamp[5]) * 0.01);
+    }
     if (dd_on) agree_flags(h);
     tm.rebuilds = dd_on ? dd_rebuilds : h.rebuild_count;
     if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
@@ -638,6 +685,7 @@ template <typename R> struct CtxT : Ctx {
     if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil exceeded the LDS tile capacity (" + std::to_string(h.stage_overflow) + " particles)");
     if (h.nl_overflow) throw ChemError(CHEM_ENOSPC, "neighbour row overflow during run: needed " + std::to_string(h.nl_overflow) + ", capacity " + std::to_string(S) + " (chem_set_nlist_capacity)");
     if (h.skin_violation) throw ChemError(CHEM_ESTATE, "internal: neighbour list used past skin/2");
+    if (h.barrier_timeout) throw ChemError(CHEM_ESTATE, "fused rebuild: grid barrier timed out (device shared with another job?); set option fused_rebuild=0");
     if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
   }
 
@@ -1370,6 +1418,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "time_pair_kernel") CTX.opt_time_pair = value != 0;
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
+  else if (k == "fused_rebuild") { CTX.opt_fused = value != 0; CTX.geom_dirty = true; }
   else if (k == "pair_block") { const int v = (int)value; REQUIRE(v == 256 || v == 512 || v == 1024, CHEM_EINVAL, "pair_block must be 256, 512 or 1024"); CTX.set_pair_bs(v); }
   else if (k == "ablate") CTX.opt_ablate = (int)value;
   else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; }

@@ -55,6 +55,9 @@ struct DevCtl {
   double step_m2;                     // max |dx|^2 of the step (after the cross-rank max in DD mode)
   int mig_error;                      // a particle left its slab by more than one layer / migration buffer overflow
   int bonded_missing;                 // a bonded partner is neither owned nor a ghost on this rank
+  int barrier_timeout;                // fused rebuild: a grid barrier gave up waiting (fatal)
+  int pad0;
+  double acc_pp[2];                   // fused rebuild: accumulated distance, double-buffered by launch parity
 };
 
 template <typename R> struct Box {
@@ -198,49 +201,76 @@ __global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned l
 template <typename R> struct MigBuf { int* count; Vec4<R>* x; Vec4<R>* v; int4* img; int* tag; int cap; };
 
 template <typename R>
+__device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R>* v4, const int* tag, int4* img4, const Box<R>& box,
+                                        int* cell_cnt, int* cell_of, int* slot_of, const MigBuf<R>& mdn, const MigBuf<R>& mup, DevCtl* ctl) {
+  // the loop bound is wave-uniform (rounded up) because the slot assignment below uses cross-lane ops
+  const int iend = i0 + n;
+  for (int ib = i0 + blockIdx.x * blockDim.x; ib < iend; ib += gridDim.x * blockDim.x) {
+    const int i = ib + threadIdx.x;
+    int cid = -1;                       // -1: lane idle or particle migrates away
+    if (i < iend) {
+      Vec4<R> x = x4[i];
+      int4 im = img4[i];
+      R* p = &x.x; int* ip = &im.x;
+      int c[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        R s = floor_r(p[d] * box.invL[d]);
+        if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
+        if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
+        if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
+        int cc = (int)(p[d] * box.cell_inv[d]);
+        int ncd = (d == 2 && box.zghost) ? box.nzg : (box.nc[d] > 0 ? box.nc[d] : 1);
+        cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
+        c[d] = cc;
+      }
+      int dir = 0;   // 0 stays, -1 leaves downwards, +1 upwards
+      if (box.zghost) {
+        // c[2] is the global layer of the folded z; the slab owns layers [z0g, z0g + own)
+        const int own = box.nc[2] - 2, gz = c[2];
+        const int gu = (box.z0g + own) % box.nzg, gd = (box.z0g - 1 + box.nzg) % box.nzg;
+        if (gz >= box.z0g && gz < box.z0g + own) c[2] = gz - box.z0g + 1;
+        else if (gz == gu) dir = 1;
+        else if (gz == gd) dir = -1;
+        else { ctl->mig_error = 1; c[2] = 1; }   // moved by more than one layer: impossible within skin/2
+      }
+      x4[i] = x; img4[i] = im;
+      if (dir) {
+        const MigBuf<R>& mb = dir < 0 ? mdn : mup;
+        const int k = atomicAdd(mb.count, 1);
+        if (k < mb.cap) { mb.x[k] = x; mb.v[k] = v4[i]; mb.img[k] = im; mb.tag[k] = tag[i]; } else ctl->mig_error = 2;
+        cell_of[i] = -1;
+      } else {
+        cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
+        cell_of[i] = cid;
+      }
+    }
+    // Slot inside the cell.  The arrays are still in the cell order of the previous rebuild, so
+    // neighbouring lanes mostly share a cell: one atomic per run of equal cells in the wave
+    // (run head adds the run length, the others take base + rank) instead of one per particle --
+    // ~18 same-address atomics per cell were the whole cost of this kernel.
+    const int lane = lane_id();
+    const int prev = __shfl_up(cid, 1);
+    const bool head = lane == 0 || prev != cid;
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long upto = hm & (~0ull >> (63 - lane));          // heads at lanes <= lane
+    const int start = 63 - __clzll((long long)upto);
+    const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
+    const int end = above ? lane + __ffsll((long long)above) : 64;        // first head after this lane
+    int base = 0;
+    if (head && cid >= 0) base = atomicAdd(&cell_cnt[cid], end - start);
+    base = __shfl(base, start);
+    if (cid >= 0) slot_of[i] = base + (lane - start);
+  }
+}
+
+template <typename R>
 __global__ __launch_bounds__(256) void k_bin(int i0, int n, Vec4<R>* __restrict__ x4, const Vec4<R>* __restrict__ v4, const int* __restrict__ tag,
                                              int4* __restrict__ img4, Box<R> box,
                                              int* __restrict__ cell_cnt, int* __restrict__ cell_of,
                                              int* __restrict__ slot_of, MigBuf<R> mdn, MigBuf<R> mup, DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
-  for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i0 + n; i += gridDim.x * blockDim.x) {
-    Vec4<R> x = x4[i];
-    int4 im = img4[i];
-    R* p = &x.x; int* ip = &im.x;
-    int c[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      R s = floor_r(p[d] * box.invL[d]);
-      if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
-      if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
-      if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
-      int cc = (int)(p[d] * box.cell_inv[d]);
-      int ncd = (d == 2 && box.zghost) ? box.nzg : (box.nc[d] > 0 ? box.nc[d] : 1);
-      cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
-      c[d] = cc;
-    }
-    int dir = 0;   // 0 stays, -1 leaves downwards, +1 upwards
-    if (box.zghost) {
-      // c[2] is the global layer of the folded z; the slab owns layers [z0g, z0g + own)
-      const int own = box.nc[2] - 2, gz = c[2];
-      const int gu = (box.z0g + own) % box.nzg, gd = (box.z0g - 1 + box.nzg) % box.nzg;
-      if (gz >= box.z0g && gz < box.z0g + own) c[2] = gz - box.z0g + 1;
-      else if (gz == gu) dir = 1;
-      else if (gz == gd) dir = -1;
-      else { ctl->mig_error = 1; c[2] = 1; }   // moved by more than one layer: impossible within skin/2
-    }
-    x4[i] = x; img4[i] = im;
-    if (dir) {
-      const MigBuf<R>& mb = dir < 0 ? mdn : mup;
-      const int k = atomicAdd(mb.count, 1);
-      if (k < mb.cap) { mb.x[k] = x; mb.v[k] = v4[i]; mb.img[k] = im; mb.tag[k] = tag[i]; } else ctl->mig_error = 2;
-      cell_of[i] = -1;
-      continue;
-    }
-    int cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
-    cell_of[i] = cid;
-    slot_of[i] = atomicAdd(&cell_cnt[cid], 1);
-  }
+  dev_bin<R>(i0, n, x4, v4, tag, img4, box, cell_cnt, cell_of, slot_of, mdn, mup, ctl);
 }
 
 // arrivals of a migration exchange are appended behind the current particles
@@ -253,35 +283,66 @@ __global__ __launch_bounds__(256) void k_append_arrivals(MigBuf<R> in, int count
 }
 
 // single-block exclusive scan of cell counts -> cell_start[0..ncell]; zeroes cell_cnt for next time.
-// 4096-element tiles, coalesced, thread-local 4-scan + wave shuffle scan + 16 wave partials.
+// Each of the 16 waves scans one contiguous 1/16 of the cells with wave shuffles only (running
+// carry, four 256-cell groups in flight, no block barrier in the loop), then one barrier publishes
+// the wave totals and a second sweep adds each wave's offset to what it wrote.
 __global__ __launch_bounds__(1024) void k_scan_cells(int ncell, int base0, int* __restrict__ cell_cnt, int* __restrict__ cell_start,
                                                      const DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
   __shared__ int wsum[16];
-  __shared__ int carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  const int w = threadIdx.x >> 6;
-  for (int base = 0; base < ncell; base += 4096) {
-    const int i0 = base + threadIdx.x * 4;
-    int v[4];
+  const int w = threadIdx.x >> 6, lane = lane_id();
+  const int per = (((ncell + 15) >> 4) + 255) & ~255;
+  const int lo = w * per, hi = min(ncell, lo + per);
+  constexpr int U = 4;
+  int carry = 0;
+  for (int b = lo; b < hi; b += 256 * U) {
+    int v[U][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { v[u] = (i0 + u < ncell) ? cell_cnt[i0 + u] : 0; if (i0 + u < ncell) cell_cnt[i0 + u] = 0; }
-    const int sum = v[0] + v[1] + v[2] + v[3];
-    int incl = sum;
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o); if (lane_id() >= o) incl += t; }
-    if (lane_id() == 63) wsum[w] = incl;
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int k = 0; k < 16; ++k) { if (k < w) woff += wsum[k]; tot += wsum[k]; }
-    int run = base0 + carry_s + woff + incl - sum;
+    for (int u = 0; u < U; ++u) {
+      const int i0 = b + u * 256 + lane * 4;
+      if (i0 + 3 < hi) {
+        const int4 t = *reinterpret_cast<const int4*>(cell_cnt + i0);
+        v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+        *reinterpret_cast<int4*>(cell_cnt + i0) = make_int4(0, 0, 0, 0);
+      } else {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { if (i0 + u < ncell) cell_start[i0 + u] = run; run += v[u]; }
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s += tot;
-    __syncthreads();
+        for (int k = 0; k < 4; ++k) { v[u][k] = 0; if (i0 + k < hi) { v[u][k] = cell_cnt[i0 + k]; cell_cnt[i0 + k] = 0; } }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i0 = b + u * 256 + lane * 4;
+      const int sum = v[u][0] + v[u][1] + v[u][2] + v[u][3];
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      int run = carry + incl - sum;
+      if (i0 + 3 < hi) {
+        int4 o4; o4.x = run; o4.y = run + v[u][0]; o4.z = o4.y + v[u][1]; o4.w = o4.z + v[u][2];
+        *reinterpret_cast<int4*>(cell_start + i0) = o4;
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i0 + k < hi) cell_start[i0 + k] = run; run += v[u][k]; }
+      }
+      carry += __shfl(incl, 63);
+    }
   }
-  if (threadIdx.x == 0) cell_start[ncell] = base0 + carry_s;
+  if (lane == 0) wsum[w] = carry;
+  __syncthreads();
+  int off = base0, tot = base0;
+  for (int k = 0; k < 16; ++k) { if (k < w) off += wsum[k]; tot += wsum[k]; }
+  if (off != 0) {
+    for (int i0 = lo + lane * 4; i0 < hi; i0 += 256) {
+      if (i0 + 3 < hi) {
+        int4 t = *reinterpret_cast<int4*>(cell_start + i0);
+        t.x += off; t.y += off; t.z += off; t.w += off;
+        *reinterpret_cast<int4*>(cell_start + i0) = t;
+      } else {
+        for (int k = 0; k < 4; ++k) if (i0 + k < hi) cell_start[i0 + k] += off;
+      }
+    }
+  }
+  if (threadIdx.x == 0) cell_start[ncell] = tot;
 }
 
 __global__ __launch_bounds__(256) void k_place(int i0, int n, const int* __restrict__ cell_of, const int* __restrict__ slot_of,
@@ -296,12 +357,8 @@ __global__ __launch_bounds__(256) void k_place(int i0, int n, const int* __restr
 // One wave per cell: rank the members by tag (canonical order inside a cell => the whole pipeline
 // is run-to-run deterministic) and gather the particle arrays into cell-sorted order.
 template <typename R>
-__global__ __launch_bounds__(256) void k_sort_gather(int ncell, const int* __restrict__ cell_start, const int* __restrict__ perm,
-                                                     const Vec4<R>* __restrict__ x4, const Vec4<R>* __restrict__ v4,
-                                                     const int* __restrict__ tag, const int4* __restrict__ img4,
-                                                     Vec4<R>* __restrict__ x4o, Vec4<R>* __restrict__ v4o,
-                                                     int* __restrict__ tago, int4* __restrict__ img4o, const DevCtl* ctl) {
-  if (!ctl->need_rebuild) return;
+__device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start, const int* perm, const Vec4<R>* x4, const Vec4<R>* v4,
+                                                const int* tag, const int4* img4, Vec4<R>* x4o, Vec4<R>* v4o, int* tago, int4* img4o) {
   const int l = lane_id();
   const int nw = gridDim.x * (blockDim.x >> 6);
   for (int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < ncell; c += nw) {
@@ -326,6 +383,16 @@ __global__ __launch_bounds__(256) void k_sort_gather(int ncell, const int* __res
       }
     }
   }
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_sort_gather(int ncell, const int* __restrict__ cell_start, const int* __restrict__ perm,
+                                                     const Vec4<R>* __restrict__ x4, const Vec4<R>* __restrict__ v4,
+                                                     const int* __restrict__ tag, const int4* __restrict__ img4,
+                                                     Vec4<R>* __restrict__ x4o, Vec4<R>* __restrict__ v4o,
+                                                     int* __restrict__ tago, int4* __restrict__ img4o, const DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  dev_sort_gather<R>(ncell, cell_start, perm, x4, v4, tag, img4, x4o, v4o, tago, img4o);
 }
 
 template <typename R>
@@ -868,22 +935,11 @@ __device__ __forceinline__ int ntiles_of(const int nc[3]) {
 // ~7x more instructions per accepted pair).
 struct ActMask { unsigned int row[kMaxTypes]; };   // bit tj of row[ti]: pair (ti,tj) has a potential
 
+// list build of ONE staged tile (T and sx filled, block synchronised): see k_nlist_tiles
 template <typename R, int BS>
-__global__ __launch_bounds__(BS, 6) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
-                                                    const TileLDS<R>* __restrict__ desc, R rl2,
-                                                    const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
-                                                    ActMask act, int all_active, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
-                                                    int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl) {
-  if (!ctl->need_rebuild) return;
-  __shared__ TileLDS<R> T;
-  CHEM_DYN_LDS(R);
-  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
-    const int tile = xcd_remap(vb, ntiles);     // gridDim.x is a multiple of 8: vb % 8 == blockIdx.x % 8
-    __syncthreads();
-    tile_load_desc<R>(T, desc, tile);
-    __syncthreads();
-    tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
-    __syncthreads();
+__device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* const sx, const int* tag, const R rl2,
+                                               const int* excl_start, const int* excl_list, const int has_excl, const ActMask& act,
+                                               unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl) {
     const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4], hbase = T.geom[5];
     unsigned short* reg16 = nl16 + (size_t)hbase * S16;
     for (int q = threadIdx.x; q < nhome; q += BS) {
@@ -1027,6 +1083,25 @@ __global__ __launch_bounds__(BS, 6) void k_nlist_tiles(int ntiles, int CAP, cons
         if (cnt > S) atomicMax(&ctl->nl_overflow, cnt);
       }
     }
+}
+
+template <typename R, int BS>
+__global__ __launch_bounds__(BS, 6) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+                                                    const TileLDS<R>* __restrict__ desc, R rl2,
+                                                    const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
+                                                    ActMask act, int all_active, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
+                                                    int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl) {
+  if (!ctl->need_rebuild) return;
+  __shared__ TileLDS<R> T;
+  CHEM_DYN_LDS(R);
+  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    const int tile = xcd_remap(vb, ntiles);     // gridDim.x is a multiple of 8: vb % 8 == blockIdx.x % 8
+    __syncthreads();
+    tile_load_desc<R>(T, desc, tile);
+    __syncthreads();
+    tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
+    __syncthreads();
+    dev_nlist_tile<R, BS>(T, sx, tag, rl2, excl_start, excl_list, has_excl, act, nl16, S16, nnh, nlist, S, nn, ctl);
   }
 }
 
@@ -1057,6 +1132,256 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int ntiles, TileLDS<R>* __re
 }
 
 // ---- pair forces on tiles --------------------------------------------------------------
+// =======================================================================================
+// Fused rebuild: decision + binning + cell scan + placement + canonical sort + copy-back + tile
+// descriptors + list build in ONE persistent launch with grid barriers.
+// Why: on this part a dependent kernel-to-kernel hand-over costs ~4.6 us, and the separate chain is
+// 9 launches that all early-exit on ~7 of 8 steps -- ~40 us of a 160 us step spent launching
+// nothing.  Here the idle path is one launch whose workgroups each fold the step's displacement
+// maxima themselves (identical inputs, identical arithmetic => identical decision, no barrier
+// needed to agree) and exit.
+// The grid is sized by the host to be fully co-resident (occupancy query x CU count, exclusive
+// device); a barrier that is not released within ~1 s sets ctl->barrier_timeout and every
+// workgroup leaves (the host reports a fatal error) instead of spinning forever.
+// =======================================================================================
+struct GridBar {
+  unsigned int grp[8][32];     // arrivals per XCD group (128-byte spacing)
+  unsigned int top[32];        // groups arrived
+  unsigned int gen[32];        // generation (release flag)
+  unsigned int tq[8][32];      // tile queue heads, one per XCD
+  long long stamp[16];         // wall_clock64 of workgroup 0 at the phase boundaries of the last rebuild (diagnostics)
+};
+
+__device__ __forceinline__ bool grid_barrier(GridBar* gb, DevCtl* ctl) {
+  __shared__ int ok_s;
+  // Every wave waits until its own stores are acknowledged by the L2; ONE thread of the workgroup
+  // then executes the device-scope release (L2 write-back, needed across XCDs) and, after the wait,
+  // the acquire (L1/L2 invalidate).  Both act on the caches, not on the issuing wave, so one per
+  // workgroup is enough -- fences from all 6144 waves made a barrier cost ~160 us.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    int ok = 1;
+    const unsigned int g = blockIdx.x & 7u;
+    const unsigned int ngrp = gridDim.x < 8u ? gridDim.x : 8u;
+    const unsigned int gsize = (gridDim.x - g + 7u) >> 3;
+    const unsigned int gen = __hip_atomic_load(&gb->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (atomicAdd(&gb->grp[g][0], 1u) == gsize - 1u) {
+      __hip_atomic_store(&gb->grp[g][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (atomicAdd(&gb->top[0], 1u) == ngrp - 1u) {
+        __hip_atomic_store(&gb->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&gb->gen[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    unsigned int spins = 0;
+    while (__hip_atomic_load(&gb->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 20)) { ctl->barrier_timeout = 1; ok = 0; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale lines before anyone reads what other XCDs wrote
+    ok_s = ok;
+  }
+  __syncthreads();
+  return ok_s != 0;
+}
+
+// exclusive scan over the block (BS threads, BS/64 <= 16 waves); returns the exclusive prefix of v,
+// *total = block sum.  Two barriers; safe to call back to back.
+template <int BS>
+__device__ __forceinline__ int block_scan_excl(int v, int* total) {
+  __shared__ int ws[16];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  __syncthreads();
+  if (lane == 63) ws[w] = incl;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < BS / 64; ++k) { if (k < w) off += ws[k]; tot += ws[k]; }
+  *total = tot;
+  return off + incl - v;
+}
+
+template <typename R> struct FusedArgs {
+  int n, ncell, ntiles, CAP, S, has_excl, criterion, par, seg_shift, tseg_shift, nblk, want32;
+  double half_skin; R rl2;
+  Vec4<R> *x4, *v4, *x4o, *v4o, *x0;
+  int *tag, *tago, *rtag; int4 *img4, *img4o;
+  int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot;
+  TileLDS<R>* desc; const int *excl_start, *excl_list;
+  unsigned short* nl16; int *nnh, *nlist, *nn;
+  unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
+  Box<R> box; ActMask act;
+};
+
+// segment offsets: s_off[k] = base + sum of tot[0..k), s_off[nseg] = grand total (nseg <= 1024)
+template <int BS>
+__device__ __forceinline__ void seg_offsets(const int* tot, int nseg, int* s_off) {
+  int carry = 0;
+  for (int base = 0; base < nseg; base += BS) {
+    const int k = base + (int)threadIdx.x;
+    const int v = k < nseg ? tot[k] : 0;
+    int t;
+    const int ex = block_scan_excl<BS>(v, &t);
+    if (k < nseg) s_off[k] = carry + ex;
+    carry += t;
+  }
+  if (threadIdx.x == 0) s_off[nseg] = carry;
+  __syncthreads();
+}
+
+// block-parallel local scans: segment `seg` = 2^shift consecutive items; loc[] = exclusive prefix inside
+// the segment, tot[seg] = segment sum.  zero != 0: the counts are cleared for the next rebuild.
+template <int BS>
+__device__ __forceinline__ void seg_scan(int* cnt, int nitem, int shift, int* loc, int* tot, bool zero) {
+  const int per = 1 << shift, nseg = (nitem + per - 1) >> shift;
+  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const int lo = seg << shift, hi = min(nitem, lo + per);
+    int carry = 0;
+    for (int base = lo; base < hi; base += BS) {
+      const int k = base + (int)threadIdx.x;
+      int v = 0;
+      if (k < hi) { v = cnt[k]; if (zero) cnt[k] = 0; }
+      int t;
+      const int ex = block_scan_excl<BS>(v, &t);
+      if (k < hi) loc[k] = carry + ex;
+      carry += t;
+    }
+    if (threadIdx.x == 0) tot[seg] = carry;
+  }
+}
+
+template <typename R, int BS>
+__global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
+  __shared__ TileLDS<R> T;
+  __shared__ int s_off[1025];
+  __shared__ unsigned long long s_m[BS / 64];
+  __shared__ int s_tile;
+  CHEM_DYN_LDS(R);
+  const int t = threadIdx.x, b = blockIdx.x, NB = gridDim.x, lane = lane_id(), w = t >> 6;
+  DevCtl* const ctl = a.ctl;
+
+  // ---- P0: decision, computed redundantly by every workgroup ----
+  unsigned long long m = 0;
+  for (int k = t; k < a.nblk; k += BS) { const unsigned long long v = a.blockmax[k]; m = v > m ? v : m; }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(m, o); m = v > m ? v : m; }
+  if (lane == 0) s_m[w] = m;
+  __syncthreads();
+  m = s_m[0];
+#pragma unroll
+  for (int k = 1; k < BS / 64; ++k) m = s_m[k] > m ? s_m[k] : m;
+  const double m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
+  double acc = a.criterion ? sqrt(m2) : ctl->acc_pp[a.par] + sqrt(m2);
+  const int need = (acc > a.half_skin) || ctl->force_rebuild;
+  if (!need) {
+    if (b == 0 && t == 0) { ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = acc; ctl->acc_maxdist = acc; ctl->need_rebuild = 0; }
+    return;
+  }
+
+  // ---- P1: bin ----
+  if (b == 0 && t == 0) a.gb->stamp[0] = wall_clock64();
+  if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
+  { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl); }
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[1] = wall_clock64();
+  // every workgroup has taken its decision: the control block may change now
+  if (b == 0 && t == 0) {
+    ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = 0.0; ctl->acc_maxdist = 0.0; ctl->force_rebuild = 0;
+    ctl->rebuild_count++; ctl->need_rebuild = 1;
+  }
+
+  // ---- P2: cell counts -> per-segment exclusive prefixes + segment totals ----
+  seg_scan<BS>(a.cell_cnt, a.ncell, a.seg_shift, a.cell_loc, a.btot, true);
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[2] = wall_clock64();
+
+  // ---- P3: final cell_start of the own segments; particle -> sorted position ----
+  {
+    const int per = 1 << a.seg_shift, nseg = (a.ncell + per - 1) >> a.seg_shift;
+    seg_offsets<BS>(a.btot, nseg, s_off);
+    for (int seg = b; seg < nseg; seg += NB) {
+      const int lo = seg << a.seg_shift, hi = min(a.ncell, lo + per);
+      for (int c = lo + t; c < hi; c += BS) a.cell_start[c] = a.cell_loc[c] + s_off[seg];
+    }
+    if (b == 0 && t == 0) a.cell_start[a.ncell] = s_off[nseg];
+    for (int i = b * BS + t; i < a.n; i += NB * BS) {
+      const int c = a.cell_of[i];
+      if (c >= 0) a.perm[a.cell_loc[c] + s_off[c >> a.seg_shift] + a.slot_of[i]] = i;
+    }
+  }
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[3] = wall_clock64();
+
+  // ---- P4: canonical order inside every cell + gather; home-particle count of every tile ----
+  dev_sort_gather<R>(a.ncell, a.cell_start, a.perm, a.x4, a.v4, a.tag, a.img4, a.x4o, a.v4o, a.tago, a.img4o);
+  {
+    const int nx = a.box.nc[0], ny = a.box.nc[1], nz = a.box.nc[2];
+    const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
+    for (int tile = b * BS + t; tile < a.ntiles; tile += NB * BS) {
+      const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+      const int cx0 = tx * HX, cy0 = ty * HY, cz0 = tz * HZ;
+      const int hx = min(HX, nx - cx0), hy = min(HY, ny - cy0), hz = min(HZ, nz - cz0);
+      int nh = 0;
+      for (int hzi = 0; hzi < hz; ++hzi) for (int hyi = 0; hyi < hy; ++hyi) {
+        const int c0 = ((cz0 + hzi) * ny + (cy0 + hyi)) * nx + cx0;
+        nh += a.cell_start[c0 + hx] - a.cell_start[c0];
+      }
+      a.tn[tile] = nh;
+    }
+  }
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[4] = wall_clock64();
+
+  // ---- P5: copy back (+ tag -> index map, reference positions), tile descriptors, tile-count scan ----
+  for (int k = b * BS + t; k < a.n; k += NB * BS) {
+    const Vec4<R> xk = a.x4o[k];
+    a.x4[k] = xk; if (a.x0) a.x0[k] = xk;
+    a.v4[k] = a.v4o[k]; a.img4[k] = a.img4o[k];
+    const int tg = a.tago[k]; a.tag[k] = tg; a.rtag[tg] = k;
+  }
+  for (int tile = b; tile < a.ntiles; tile += NB) {
+    __syncthreads();
+    tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl);
+    const int* src = reinterpret_cast<const int*>(&T);
+    int* dst = reinterpret_cast<int*>(&a.desc[tile]);
+    for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
+  }
+  seg_scan<BS>(a.tn, a.ntiles, a.tseg_shift, a.tloc, a.tbtot, false);
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[5] = wall_clock64();
+
+  // ---- P6: list build; tiles are handed out dynamically, each XCD first drains its own contiguous
+  //          range of tiles (L2 locality, see xcd_remap) and then helps the others ----
+  {
+    const int tper = 1 << a.tseg_shift, ntseg = (a.ntiles + tper - 1) >> a.tseg_shift;
+    seg_offsets<BS>(a.tbtot, ntseg, s_off);
+    const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
+    for (;;) {
+      __syncthreads();
+      if (t == 0) {
+        int tile = -1;
+        for (int d = 0; d < 8 && tile < 0; ++d) {
+          const int x = (myx + d) & 7;
+          const int cntx = q + (x < r ? 1 : 0);
+          if (__hip_atomic_load(&a.gb->tq[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)cntx) continue;
+          const int k = (int)atomicAdd(&a.gb->tq[x][0], 1u);
+          if (k < cntx) tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+        }
+        s_tile = tile;
+      }
+      __syncthreads();
+      const int tile = s_tile;
+      if (tile < 0) break;
+      tile_load_desc<R>(T, a.desc, tile);
+      __syncthreads();
+      if (t == 0) { const int hb = a.tloc[tile] + s_off[tile >> a.tseg_shift]; T.geom[5] = hb; a.desc[tile].geom[5] = hb; }
+      tile_fill<R, BS, true>(T, sx, a.CAP, a.x4, 1);
+      __syncthreads();
+      dev_nlist_tile<R, BS>(T, sx, a.tag, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
+                            a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl);
+    }
+  }
+  if (b == 0 && t == 0) a.gb->stamp[6] = wall_clock64();
+}
+
 template <typename R, bool ENERGY, bool LJONLY>
 __device__ __forceinline__ void pair_accum(const PairCore<R> pc, const PairExt<R>* __restrict__ pext, int pidx,
                                            const Vec4<R>* __restrict__ tab, R r2, R dx, R dy, R dz,
