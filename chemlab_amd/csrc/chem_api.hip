@@ -121,6 +121,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
   // fused rebuild (single domain, tiles): segment scans + grid barrier state
   DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot; DBuf<GridBar> gbar;
+  DBuf<int2> bse; DBuf<int4> bj; bool bwork_dirty = true;   // bonded work list (see dev_bonded_prep)
   int fused_grid = 0, fused_par = 0, seg_shift = 0, tseg_shift = 0; bool use_fused = false;
   DBuf<int> nlist, nn, nnh;
   DBuf<unsigned short> nl16;
@@ -258,6 +259,7 @@ template <typename R> struct CtxT : Ctx {
     a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
     a.desc = tdesc.p; a.excl_start = excl_start.p; a.excl_list = excl_list.p; a.nl16 = nl16.p; a.nnh = nnh.p; a.nlist = nlist.p; a.nn = nn.p;
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
+    a.bstart = bstart.p; a.bent = bent.p; a.bse = bse.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
     hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), tile_lds_bytes(), stream, a);
     fused_par ^= 1;
   }
@@ -433,6 +435,8 @@ template <typename R> struct CtxT : Ctx {
     if (!hp.empty()) HIPCHK(hipMemcpyAsync(bpar.p, hp.data(), hp.size() * sizeof(BondedParam), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
     nbent = (int64_t)he.size();
+    bse.alloc((size_t)std::max(acap(), 1)); bj.alloc(std::max<size_t>(he.size(), 1));
+    bwork_dirty = true;
     bonded_dirty = false;
   }
 
@@ -649,7 +653,14 @@ template <typename R> struct CtxT : Ctx {
     if (timed) HIPCHK(hipEventRecord(ev[ev_used], stream));
     launch_pair<false>(f4.p, tpp);
     if (timed) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; }
-    if (nbent > 0)
+    if (nbent > 0 && use_fused) {
+      // work-list kernel: owners only, partner indices resolved at the last rebuild
+      if (bwork_dirty) {   // bonded lists changed without a rebuild since
+        hipLaunchKernelGGL(k_bonded_prep, dim3(std::min(cdiv(n, 256), 2048)), dim3(256), 0, stream, 0, n, tag.p, rtag.p, bstart.p, bent.p, bse.p, bj.p);
+        bwork_dirty = false;
+      }
+      hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n, x4.p, f4.p, bse.p, bj.p, bent.p, bpar.p, boxd, ctl.p);
+    } else if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
                          bpar.p, boxd, elist.p, ctl.p);
   }
@@ -685,6 +696,7 @@ template <typename R> struct CtxT : Ctx {
     if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil exceeded the LDS tile capacity (" + std::to_string(h.stage_overflow) + " particles)");
     if (h.nl_overflow) throw ChemError(CHEM_ENOSPC, "neighbour row overflow during run: needed " + std::to_string(h.nl_overflow) + ", capacity " + std::to_string(S) + " (chem_set_nlist_capacity)");
     if (h.skin_violation) throw ChemError(CHEM_ESTATE, "internal: neighbour list used past skin/2");
+    if (h.excl_slot_error) throw ChemError(CHEM_ESTATE, "internal: list build could not locate an excluded partner in its cell");
     if (h.barrier_timeout) throw ChemError(CHEM_ESTATE, "fused rebuild: grid barrier timed out (device shared with another job?); set option fused_rebuild=0");
     if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
   }

@@ -58,6 +58,8 @@ struct DevCtl {
   int barrier_timeout;                // fused rebuild: a grid barrier gave up waiting (fatal)
   int pad0;
   double acc_pp[2];                   // fused rebuild: accumulated distance, double-buffered by launch parity
+  int bwork_count;                    // (unused)
+  int excl_slot_error;                // list build: an excluded partner was not found in the cell computed from its position (internal)
 };
 
 template <typename R> struct Box {
@@ -726,7 +728,7 @@ template <typename R> struct TileLDS {
   R cellshx[NROW][SX];                 // periodic shift in x (per cell), y/z (per row)
   R rowshy[NROW], rowshz[NROW];
   int hstart[NHSEG], hoff[NHSEG + 1];  // home x-runs: global start, prefix of counts
-  int geom[8];                         // hx, hy, hz, total, nhome
+  int geom[8];                         // hx, hy, hz, total, nhome, hbase, origin cell (10 bits per axis)
 };
 
 // NOTE: the pointer must stay a plain local derived from the extern array (no integer
@@ -791,6 +793,7 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
     }
     T.hoff[NHSEG] = ho;
     T.geom[0] = hx; T.geom[1] = hy; T.geom[2] = hz; T.geom[3] = total; T.geom[4] = ho;
+    T.geom[6] = cx0 | (cy0 << 10) | (cz0 << 20);   // first home cell (list build: slot of an excluded partner)
   }
   __syncthreads();
 }
@@ -939,7 +942,8 @@ struct ActMask { unsigned int row[kMaxTypes]; };   // bit tj of row[ti]: pair (t
 template <typename R, int BS>
 __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* const sx, const int* tag, const R rl2,
                                                const int* excl_start, const int* excl_list, const int has_excl, const ActMask& act,
-                                               unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl) {
+                                               unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl,
+                                               const Box<R>* bx = nullptr, const int* rtag = nullptr, const Vec4<R>* x4 = nullptr) {
     const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4], hbase = T.geom[5];
     unsigned short* reg16 = nl16 + (size_t)hbase * S16;
     for (int q = threadIdx.x; q < nhome; q += BS) {
@@ -960,7 +964,41 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
       if (has_excl) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
       int cnt = 0, cnt16 = 0;
       int* row32 = nlist ? nlist + (size_t)p * S : nullptr;
-      const bool plain = e1 == e0 && !row32;
+      // Exclusions without leaving the plain path (single domain): the few excluded partners of a
+      // particle are located in the staged tile ONCE (tag -> index -> position -> cell -> slot, the
+      // binning arithmetic repeated on the same bits) and their bits are cleared from the hit masks,
+      // like the self pair.  Otherwise every hit of a bonded particle would need the candidate's tag
+      // from global memory.  More than 4 exclusions: generic path below.
+      int xs0 = -1, xs1 = -1, xs2 = -1, xs3 = -1;
+      bool fastx = false;
+      if (bx && e1 > e0 && e1 - e0 <= 4 && !row32) {
+        fastx = true;
+        const int org = T.geom[6];
+        const int nx = bx->nc[0], ny = bx->nc[1], nz = bx->nc[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          int slot = -1;
+          if (e0 + k < e1) {
+            const int g = rtag[excl_list[e0 + k]];
+            if (g >= 0) {
+              const Vec4<R> xg = x4[g];
+              int cx = (int)(xg.x * bx->cell_inv[0]), cy = (int)(xg.y * bx->cell_inv[1]), cz = (int)(xg.z * bx->cell_inv[2]);
+              cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx); cy = cy >= ny ? ny - 1 : (cy < 0 ? 0 : cy); cz = cz >= nz ? nz - 1 : (cz < 0 ? 0 : cz);
+              int kx = cx - (org & 1023) + 1, ky = cy - ((org >> 10) & 1023) + 1, kz = cz - (org >> 20) + 1;
+              kx += kx < 0 ? nx : 0; kx -= kx >= nx ? nx : 0;
+              ky += ky < 0 ? ny : 0; ky -= ky >= ny ? ny : 0;
+              kz += kz < 0 ? nz : 0; kz -= kz >= nz ? nz : 0;
+              if (kx < hx + 2 && ky < T.geom[1] + 2 && kz < T.geom[2] + 2) {
+                const int rr = kz * SY + ky, off = g - T.cellg[rr][kx];
+                if (off >= 0 && off < T.celloff[rr][kx + 1] - T.celloff[rr][kx]) slot = T.rowoff[rr] + T.celloff[rr][kx] + off;
+                else ctl->excl_slot_error = 1;
+              }
+            }
+          }
+          if (k == 0) xs0 = slot; else if (k == 1) xs1 = slot; else if (k == 2) xs2 = slot; else xs3 = slot;
+        }
+      }
+      const bool plain = (e1 == e0 || fastx) && !row32;
       uint4* regq = reinterpret_cast<uint4*>(reg16) + q;   // chunk c of this particle: regq[c * nhome]
       // accepted slots are shifted into a 128-bit register; every 8th append stores one whole
       // 16-byte chunk (instead of eight scattered 2-byte stores)
@@ -1030,6 +1068,13 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
               m &= ma << (32 - 4 * ng);
               const unsigned int ks = (unsigned int)(sself - s0);
               if (ks < 32u) m &= ~(0x80000000u >> ks);
+              if (fastx) {
+                const unsigned int k0 = (unsigned int)(xs0 - s0), k1 = (unsigned int)(xs1 - s0), k2 = (unsigned int)(xs2 - s0), k3 = (unsigned int)(xs3 - s0);
+                if (k0 < 32u) m &= ~(0x80000000u >> k0);
+                if (k1 < 32u) m &= ~(0x80000000u >> k1);
+                if (k2 < 32u) m &= ~(0x80000000u >> k2);
+                if (k3 < 32u) m &= ~(0x80000000u >> k3);
+              }
               while (m) {
                 const int k = __clz((int)m);
                 m &= ~(0x80000000u >> k);
@@ -1132,256 +1177,6 @@ __global__ __launch_bounds__(1024) void k_tile_scan(int ntiles, TileLDS<R>* __re
 }
 
 // ---- pair forces on tiles --------------------------------------------------------------
-// =======================================================================================
-// Fused rebuild: decision + binning + cell scan + placement + canonical sort + copy-back + tile
-// descriptors + list build in ONE persistent launch with grid barriers.
-// Why: on this part a dependent kernel-to-kernel hand-over costs ~4.6 us, and the separate chain is
-// 9 launches that all early-exit on ~7 of 8 steps -- ~40 us of a 160 us step spent launching
-// nothing.  Here the idle path is one launch whose workgroups each fold the step's displacement
-// maxima themselves (identical inputs, identical arithmetic => identical decision, no barrier
-// needed to agree) and exit.
-// The grid is sized by the host to be fully co-resident (occupancy query x CU count, exclusive
-// device); a barrier that is not released within ~1 s sets ctl->barrier_timeout and every
-// workgroup leaves (the host reports a fatal error) instead of spinning forever.
-// =======================================================================================
-struct GridBar {
-  unsigned int grp[8][32];     // arrivals per XCD group (128-byte spacing)
-  unsigned int top[32];        // groups arrived
-  unsigned int gen[32];        // generation (release flag)
-  unsigned int tq[8][32];      // tile queue heads, one per XCD
-  long long stamp[16];         // wall_clock64 of workgroup 0 at the phase boundaries of the last rebuild (diagnostics)
-};
-
-__device__ __forceinline__ bool grid_barrier(GridBar* gb, DevCtl* ctl) {
-  __shared__ int ok_s;
-  // Every wave waits until its own stores are acknowledged by the L2; ONE thread of the workgroup
-  // then executes the device-scope release (L2 write-back, needed across XCDs) and, after the wait,
-  // the acquire (L1/L2 invalidate).  Both act on the caches, not on the issuing wave, so one per
-  // workgroup is enough -- fences from all 6144 waves made a barrier cost ~160 us.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    int ok = 1;
-    const unsigned int g = blockIdx.x & 7u;
-    const unsigned int ngrp = gridDim.x < 8u ? gridDim.x : 8u;
-    const unsigned int gsize = (gridDim.x - g + 7u) >> 3;
-    const unsigned int gen = __hip_atomic_load(&gb->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (atomicAdd(&gb->grp[g][0], 1u) == gsize - 1u) {
-      __hip_atomic_store(&gb->grp[g][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (atomicAdd(&gb->top[0], 1u) == ngrp - 1u) {
-        __hip_atomic_store(&gb->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(&gb->gen[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    unsigned int spins = 0;
-    while (__hip_atomic_load(&gb->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > (1u << 20)) { ctl->barrier_timeout = 1; ok = 0; break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale lines before anyone reads what other XCDs wrote
-    ok_s = ok;
-  }
-  __syncthreads();
-  return ok_s != 0;
-}
-
-// exclusive scan over the block (BS threads, BS/64 <= 16 waves); returns the exclusive prefix of v,
-// *total = block sum.  Two barriers; safe to call back to back.
-template <int BS>
-__device__ __forceinline__ int block_scan_excl(int v, int* total) {
-  __shared__ int ws[16];
-  const int lane = lane_id(), w = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-  __syncthreads();
-  if (lane == 63) ws[w] = incl;
-  __syncthreads();
-  int off = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < BS / 64; ++k) { if (k < w) off += ws[k]; tot += ws[k]; }
-  *total = tot;
-  return off + incl - v;
-}
-
-template <typename R> struct FusedArgs {
-  int n, ncell, ntiles, CAP, S, has_excl, criterion, par, seg_shift, tseg_shift, nblk, want32;
-  double half_skin; R rl2;
-  Vec4<R> *x4, *v4, *x4o, *v4o, *x0;
-  int *tag, *tago, *rtag; int4 *img4, *img4o;
-  int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot;
-  TileLDS<R>* desc; const int *excl_start, *excl_list;
-  unsigned short* nl16; int *nnh, *nlist, *nn;
-  unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
-  Box<R> box; ActMask act;
-};
-
-// segment offsets: s_off[k] = base + sum of tot[0..k), s_off[nseg] = grand total (nseg <= 1024)
-template <int BS>
-__device__ __forceinline__ void seg_offsets(const int* tot, int nseg, int* s_off) {
-  int carry = 0;
-  for (int base = 0; base < nseg; base += BS) {
-    const int k = base + (int)threadIdx.x;
-    const int v = k < nseg ? tot[k] : 0;
-    int t;
-    const int ex = block_scan_excl<BS>(v, &t);
-    if (k < nseg) s_off[k] = carry + ex;
-    carry += t;
-  }
-  if (threadIdx.x == 0) s_off[nseg] = carry;
-  __syncthreads();
-}
-
-// block-parallel local scans: segment `seg` = 2^shift consecutive items; loc[] = exclusive prefix inside
-// the segment, tot[seg] = segment sum.  zero != 0: the counts are cleared for the next rebuild.
-template <int BS>
-__device__ __forceinline__ void seg_scan(int* cnt, int nitem, int shift, int* loc, int* tot, bool zero) {
-  const int per = 1 << shift, nseg = (nitem + per - 1) >> shift;
-  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
-    const int lo = seg << shift, hi = min(nitem, lo + per);
-    int carry = 0;
-    for (int base = lo; base < hi; base += BS) {
-      const int k = base + (int)threadIdx.x;
-      int v = 0;
-      if (k < hi) { v = cnt[k]; if (zero) cnt[k] = 0; }
-      int t;
-      const int ex = block_scan_excl<BS>(v, &t);
-      if (k < hi) loc[k] = carry + ex;
-      carry += t;
-    }
-    if (threadIdx.x == 0) tot[seg] = carry;
-  }
-}
-
-template <typename R, int BS>
-__global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
-  __shared__ TileLDS<R> T;
-  __shared__ int s_off[1025];
-  __shared__ unsigned long long s_m[BS / 64];
-  __shared__ int s_tile;
-  CHEM_DYN_LDS(R);
-  const int t = threadIdx.x, b = blockIdx.x, NB = gridDim.x, lane = lane_id(), w = t >> 6;
-  DevCtl* const ctl = a.ctl;
-
-  // ---- P0: decision, computed redundantly by every workgroup ----
-  unsigned long long m = 0;
-  for (int k = t; k < a.nblk; k += BS) { const unsigned long long v = a.blockmax[k]; m = v > m ? v : m; }
-  for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(m, o); m = v > m ? v : m; }
-  if (lane == 0) s_m[w] = m;
-  __syncthreads();
-  m = s_m[0];
-#pragma unroll
-  for (int k = 1; k < BS / 64; ++k) m = s_m[k] > m ? s_m[k] : m;
-  const double m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
-  double acc = a.criterion ? sqrt(m2) : ctl->acc_pp[a.par] + sqrt(m2);
-  const int need = (acc > a.half_skin) || ctl->force_rebuild;
-  if (!need) {
-    if (b == 0 && t == 0) { ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = acc; ctl->acc_maxdist = acc; ctl->need_rebuild = 0; }
-    return;
-  }
-
-  // ---- P1: bin ----
-  if (b == 0 && t == 0) a.gb->stamp[0] = wall_clock64();
-  if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
-  { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl); }
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[1] = wall_clock64();
-  // every workgroup has taken its decision: the control block may change now
-  if (b == 0 && t == 0) {
-    ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = 0.0; ctl->acc_maxdist = 0.0; ctl->force_rebuild = 0;
-    ctl->rebuild_count++; ctl->need_rebuild = 1;
-  }
-
-  // ---- P2: cell counts -> per-segment exclusive prefixes + segment totals ----
-  seg_scan<BS>(a.cell_cnt, a.ncell, a.seg_shift, a.cell_loc, a.btot, true);
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[2] = wall_clock64();
-
-  // ---- P3: final cell_start of the own segments; particle -> sorted position ----
-  {
-    const int per = 1 << a.seg_shift, nseg = (a.ncell + per - 1) >> a.seg_shift;
-    seg_offsets<BS>(a.btot, nseg, s_off);
-    for (int seg = b; seg < nseg; seg += NB) {
-      const int lo = seg << a.seg_shift, hi = min(a.ncell, lo + per);
-      for (int c = lo + t; c < hi; c += BS) a.cell_start[c] = a.cell_loc[c] + s_off[seg];
-    }
-    if (b == 0 && t == 0) a.cell_start[a.ncell] = s_off[nseg];
-    for (int i = b * BS + t; i < a.n; i += NB * BS) {
-      const int c = a.cell_of[i];
-      if (c >= 0) a.perm[a.cell_loc[c] + s_off[c >> a.seg_shift] + a.slot_of[i]] = i;
-    }
-  }
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[3] = wall_clock64();
-
-  // ---- P4: canonical order inside every cell + gather; home-particle count of every tile ----
-  dev_sort_gather<R>(a.ncell, a.cell_start, a.perm, a.x4, a.v4, a.tag, a.img4, a.x4o, a.v4o, a.tago, a.img4o);
-  {
-    const int nx = a.box.nc[0], ny = a.box.nc[1], nz = a.box.nc[2];
-    const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
-    for (int tile = b * BS + t; tile < a.ntiles; tile += NB * BS) {
-      const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
-      const int cx0 = tx * HX, cy0 = ty * HY, cz0 = tz * HZ;
-      const int hx = min(HX, nx - cx0), hy = min(HY, ny - cy0), hz = min(HZ, nz - cz0);
-      int nh = 0;
-      for (int hzi = 0; hzi < hz; ++hzi) for (int hyi = 0; hyi < hy; ++hyi) {
-        const int c0 = ((cz0 + hzi) * ny + (cy0 + hyi)) * nx + cx0;
-        nh += a.cell_start[c0 + hx] - a.cell_start[c0];
-      }
-      a.tn[tile] = nh;
-    }
-  }
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[4] = wall_clock64();
-
-  // ---- P5: copy back (+ tag -> index map, reference positions), tile descriptors, tile-count scan ----
-  for (int k = b * BS + t; k < a.n; k += NB * BS) {
-    const Vec4<R> xk = a.x4o[k];
-    a.x4[k] = xk; if (a.x0) a.x0[k] = xk;
-    a.v4[k] = a.v4o[k]; a.img4[k] = a.img4o[k];
-    const int tg = a.tago[k]; a.tag[k] = tg; a.rtag[tg] = k;
-  }
-  for (int tile = b; tile < a.ntiles; tile += NB) {
-    __syncthreads();
-    tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl);
-    const int* src = reinterpret_cast<const int*>(&T);
-    int* dst = reinterpret_cast<int*>(&a.desc[tile]);
-    for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
-  }
-  seg_scan<BS>(a.tn, a.ntiles, a.tseg_shift, a.tloc, a.tbtot, false);
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[5] = wall_clock64();
-
-  // ---- P6: list build; tiles are handed out dynamically, each XCD first drains its own contiguous
-  //          range of tiles (L2 locality, see xcd_remap) and then helps the others ----
-  {
-    const int tper = 1 << a.tseg_shift, ntseg = (a.ntiles + tper - 1) >> a.tseg_shift;
-    seg_offsets<BS>(a.tbtot, ntseg, s_off);
-    const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
-    for (;;) {
-      __syncthreads();
-      if (t == 0) {
-        int tile = -1;
-        for (int d = 0; d < 8 && tile < 0; ++d) {
-          const int x = (myx + d) & 7;
-          const int cntx = q + (x < r ? 1 : 0);
-          if (__hip_atomic_load(&a.gb->tq[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)cntx) continue;
-          const int k = (int)atomicAdd(&a.gb->tq[x][0], 1u);
-          if (k < cntx) tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-        }
-        s_tile = tile;
-      }
-      __syncthreads();
-      const int tile = s_tile;
-      if (tile < 0) break;
-      tile_load_desc<R>(T, a.desc, tile);
-      __syncthreads();
-      if (t == 0) { const int hb = a.tloc[tile] + s_off[tile >> a.tseg_shift]; T.geom[5] = hb; a.desc[tile].geom[5] = hb; }
-      tile_fill<R, BS, true>(T, sx, a.CAP, a.x4, 1);
-      __syncthreads();
-      dev_nlist_tile<R, BS>(T, sx, a.tag, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
-                            a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl);
-    }
-  }
-  if (b == 0 && t == 0) a.gb->stamp[6] = wall_clock64();
-}
-
 template <typename R, bool ENERGY, bool LJONLY>
 __device__ __forceinline__ void pair_accum(const PairCore<R> pc, const PairExt<R>* __restrict__ pext, int pidx,
                                            const Vec4<R>* __restrict__ tab, R r2, R dx, R dy, R dz,
@@ -1533,27 +1328,15 @@ __device__ __forceinline__ D3 minimgD(const BoxD& b, D3 d) {
 }
 template <typename R> __device__ __forceinline__ D3 posD(const Vec4<R>& v) { return {(double)v.x, (double)v.y, (double)v.z}; }
 
+// one bonded term seen from member `me` of the tuple (j0..j3 = particle indices of the tuple in order)
 template <typename R, bool ENERGY>
-__global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
-                                                const int* __restrict__ tag, const int* __restrict__ rtag,
-                                                const int* __restrict__ bstart, const BondedEntry* __restrict__ bent,
-                                                const BondedParam* __restrict__ bpar, BoxD box, double* __restrict__ elist, DevCtl* ctl) {
-  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= i0 + n) return;
-  const int tg = tag[i];
-  const int e0 = bstart[tg], e1 = bstart[tg + 1];
-  if (e0 == e1) return;
-  D3 f = {0, 0, 0};
-  for (int e = e0; e < e1; ++e) {
-    const BondedEntry be = bent[e];
-    const int slot = be.meta & 0x0fffffff, me = (be.meta >> 28) & 3;
-    const BondedParam bp = bpar[slot];
+__device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me, const int j0, const int j1, const int j2, const int j3,
+                                            const Vec4<R>* __restrict__ x4, const BoxD& box, D3& f, double* __restrict__ elist, DevCtl* ctl) {
     const double* p = bp.p;
     double u = 0;
     if (bp.arity == 2) {
       // tuple (t0,t1); r_ij = x_t0 - x_t1
-      const int j0 = rtag[be.t0], j1 = rtag[be.t1];
-      if ((j0 | j1) < 0) { ctl->bonded_missing = 1; continue; }
+      if ((j0 | j1) < 0) { ctl->bonded_missing = 1; return; }
       const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]);
       const D3 d = minimgD(box, x0 - x1);
       const double r = sqrt(dot3(d, d));
@@ -1563,8 +1346,7 @@ __global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __
       const double sgn = me == 0 ? 1.0 : -1.0;
       f = f + (sgn * ff) * d;
     } else if (bp.arity == 3) {
-      const int j0 = rtag[be.t0], j1 = rtag[be.t1], j2 = rtag[be.t2];
-      if ((j0 | j1 | j2) < 0) { ctl->bonded_missing = 1; continue; }
+      if ((j0 | j1 | j2) < 0) { ctl->bonded_missing = 1; return; }
       const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]), x2 = posD<R>(x4[j2]);
       const D3 r1 = minimgD(box, x0 - x1), r2 = minimgD(box, x2 - x1);
       const double n1 = sqrt(dot3(r1, r1)), n2 = sqrt(dot3(r2, r2));
@@ -1581,15 +1363,12 @@ __global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __
       const D3 fk = a * ((1.0 / (n1 * n2)) * r1 - (c / (n2 * n2)) * r2);
       if (me == 0) f = f + fi; else if (me == 2) f = f + fk; else f = f - (fi + fk);
     } else {
-      const BondedEntry be2 = bent[e + 1];  // quadruples occupy two consecutive entries: (t0,t1,t2,meta),(t3,-,-,-)
-      const int j0 = rtag[be.t0], j1 = rtag[be.t1], j2 = rtag[be.t2], j3 = rtag[be2.t0];
-      ++e;
-      if ((j0 | j1 | j2 | j3) < 0) { ctl->bonded_missing = 1; continue; }
+      if ((j0 | j1 | j2 | j3) < 0) { ctl->bonded_missing = 1; return; }
       const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]), x2 = posD<R>(x4[j2]), x3 = posD<R>(x4[j3]);
       const D3 b1 = minimgD(box, x1 - x0), b2 = minimgD(box, x2 - x1), b3 = minimgD(box, x3 - x2);
       const D3 m = cross3(b1, b2), nn = cross3(b2, b3);
       const double m2 = dot3(m, m), n2 = dot3(nn, nn), lb2 = dot3(b2, b2), lb = sqrt(lb2);
-      if (m2 < 1e-30 || n2 < 1e-30) continue;
+      if (m2 < 1e-30 || n2 < 1e-30) return;
       const double phi = atan2(lb * dot3(b1, nn), dot3(m, nn));
       double dU = 0;
       if (bp.kind == CHEM_POT_DIH_NCOS) { u = p[0] * (1.0 + cos(p[2] * phi - p[1])); dU = -p[0] * p[2] * sin(p[2] * phi - p[1]); }
@@ -1609,10 +1388,325 @@ __global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __
       f = f - dU * g;
     }
     if (ENERGY && me == 0) atomicAdd(&elist[bp.list], u);
+}
+
+template <typename R, bool ENERGY>
+__global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
+                                                const int* __restrict__ tag, const int* __restrict__ rtag,
+                                                const int* __restrict__ bstart, const BondedEntry* __restrict__ bent,
+                                                const BondedParam* __restrict__ bpar, BoxD box, double* __restrict__ elist, DevCtl* ctl) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i0 + n) return;
+  const int tg = tag[i];
+  const int e0 = bstart[tg], e1 = bstart[tg + 1];
+  if (e0 == e1) return;
+  D3 f = {0, 0, 0};
+  for (int e = e0; e < e1; ++e) {
+    const BondedEntry be = bent[e];
+    const int slot = be.meta & 0x0fffffff, me = (be.meta >> 28) & 3;
+    const BondedParam& bp = bpar[slot];
+    const int ar = bp.arity;
+    const int j0 = rtag[be.t0], j1 = rtag[be.t1], j2 = ar > 2 ? rtag[be.t2] : 0;
+    int j3 = 0;
+    if (ar == 4) { j3 = rtag[bent[e + 1].t0]; ++e; }   // quadruples occupy two consecutive entries: (t0,t1,t2,meta),(t3,-,-,-)
+    bonded_term<R, ENERGY>(bp, me, j0, j1, j2, j3, x4, box, f, elist, ctl);
   }
   Vec4<R> fo = f4[i];
   fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;
   f4[i] = fo;
+}
+
+// ---- bonded work list: rebuilt together with the Verlet list (the particle order only changes
+// there).  bse[i] = entry range of the particle at index i, bj = the entries' partner tags already
+// resolved to particle indices.  The per-step kernel has one coalesced load in front of the early
+// exit and two dependent loads in front of the arithmetic instead of five.
+__device__ __forceinline__ void dev_bonded_prep(int i0, int n, const int* tag, const int* rtag, const int* bstart, const BondedEntry* bent,
+                                                int2* bse, int4* bj) {
+  for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i0 + n; i += gridDim.x * blockDim.x) {
+    const int tg = tag[i];
+    const int e0 = bstart[tg], e1 = bstart[tg + 1];
+    bse[i] = make_int2(e0, e1);
+    for (int e = e0; e < e1; ++e) { const BondedEntry be = bent[e]; bj[e] = make_int4(rtag[be.t0], rtag[be.t1], rtag[be.t2], 0); }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* __restrict__ tag, const int* __restrict__ rtag, const int* __restrict__ bstart,
+                                                     const BondedEntry* __restrict__ bent, int2* __restrict__ bse, int4* __restrict__ bj) {
+  dev_bonded_prep(i0, n, tag, rtag, bstart, bent, bse, bj);
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void k_bonded_work(int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int2* __restrict__ bse, const int4* __restrict__ bj,
+                                                     const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int2 se = bse[i];
+  if (se.x == se.y) return;
+  D3 f = {0, 0, 0};
+  for (int e = se.x; e < se.y; ++e) {
+    const int meta = bent[e].meta;
+    const int4 jj = bj[e];
+    const int slot = meta & 0x0fffffff, me = (meta >> 28) & 3;
+    const BondedParam& bp = bpar[slot];
+    int j3 = 0;
+    if (bp.arity == 4) { j3 = bj[e + 1].x; ++e; }
+    bonded_term<R, false>(bp, me, jj.x, jj.y, bp.arity > 2 ? jj.z : 0, j3, x4, box, f, nullptr, ctl);
+  }
+  Vec4<R> fo = f4[i];
+  fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;
+  f4[i] = fo;
+}
+
+// =======================================================================================
+// Fused rebuild: decision + binning + cell scan + placement + canonical sort + copy-back + tile
+// descriptors + list build in ONE persistent launch with grid barriers.
+// Why: on this part a dependent kernel-to-kernel hand-over costs ~4.6 us, and the separate chain is
+// 9 launches that all early-exit on ~7 of 8 steps -- ~40 us of a 160 us step spent launching
+// nothing.  Here the idle path is one launch whose workgroups each fold the step's displacement
+// maxima themselves (identical inputs, identical arithmetic => identical decision, no barrier
+// needed to agree) and exit.
+// The grid is sized by the host to be fully co-resident (occupancy query x CU count, exclusive
+// device); a barrier that is not released within ~1 s sets ctl->barrier_timeout and every
+// workgroup leaves (the host reports a fatal error) instead of spinning forever.
+// =======================================================================================
+struct GridBar {
+  unsigned int grp[8][32];     // arrivals per XCD group (128-byte spacing)
+  unsigned int top[32];        // groups arrived
+  unsigned int gen[32];        // generation (release flag)
+  unsigned int tq[8][32];      // tile queue heads, one per XCD
+  long long stamp[16];         // wall_clock64 of workgroup 0 at the phase boundaries of the last rebuild (diagnostics)
+};
+
+__device__ __forceinline__ bool grid_barrier(GridBar* gb, DevCtl* ctl) {
+  __shared__ int ok_s;
+  // Every wave waits until its own stores are acknowledged by the L2; ONE thread of the workgroup
+  // then executes the device-scope release (L2 write-back, needed across XCDs) and, after the wait,
+  // the acquire (L1/L2 invalidate).  Both act on the caches, not on the issuing wave, so one per
+  // workgroup is enough -- fences from all 6144 waves made a barrier cost ~160 us.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    int ok = 1;
+    const unsigned int g = blockIdx.x & 7u;
+    const unsigned int ngrp = gridDim.x < 8u ? gridDim.x : 8u;
+    const unsigned int gsize = (gridDim.x - g + 7u) >> 3;
+    const unsigned int gen = __hip_atomic_load(&gb->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (atomicAdd(&gb->grp[g][0], 1u) == gsize - 1u) {
+      __hip_atomic_store(&gb->grp[g][0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (atomicAdd(&gb->top[0], 1u) == ngrp - 1u) {
+        __hip_atomic_store(&gb->top[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&gb->gen[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    unsigned int spins = 0;
+    while (__hip_atomic_load(&gb->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 20)) { ctl->barrier_timeout = 1; ok = 0; break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop stale lines before anyone reads what other XCDs wrote
+    ok_s = ok;
+  }
+  __syncthreads();
+  return ok_s != 0;
+}
+
+// exclusive scan over the block (BS threads, BS/64 <= 16 waves); returns the exclusive prefix of v,
+// *total = block sum.  Two barriers; safe to call back to back.
+template <int BS>
+__device__ __forceinline__ int block_scan_excl(int v, int* total) {
+  __shared__ int ws[16];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  __syncthreads();
+  if (lane == 63) ws[w] = incl;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < BS / 64; ++k) { if (k < w) off += ws[k]; tot += ws[k]; }
+  *total = tot;
+  return off + incl - v;
+}
+
+template <typename R> struct FusedArgs {
+  int n, ncell, ntiles, CAP, S, has_excl, criterion, par, seg_shift, tseg_shift, nblk, want32;
+  double half_skin; R rl2;
+  Vec4<R> *x4, *v4, *x4o, *v4o, *x0;
+  int *tag, *tago, *rtag; int4 *img4, *img4o;
+  int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot;
+  TileLDS<R>* desc; const int *excl_start, *excl_list;
+  unsigned short* nl16; int *nnh, *nlist, *nn;
+  unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
+  const int* bstart; const BondedEntry* bent; int2* bse; int4* bj; int nbent;
+  Box<R> box; ActMask act;
+};
+
+// segment offsets: s_off[k] = base + sum of tot[0..k), s_off[nseg] = grand total (nseg <= 1024)
+template <int BS>
+__device__ __forceinline__ void seg_offsets(const int* tot, int nseg, int* s_off) {
+  int carry = 0;
+  for (int base = 0; base < nseg; base += BS) {
+    const int k = base + (int)threadIdx.x;
+    const int v = k < nseg ? tot[k] : 0;
+    int t;
+    const int ex = block_scan_excl<BS>(v, &t);
+    if (k < nseg) s_off[k] = carry + ex;
+    carry += t;
+  }
+  if (threadIdx.x == 0) s_off[nseg] = carry;
+  __syncthreads();
+}
+
+// block-parallel local scans: segment `seg` = 2^shift consecutive items; loc[] = exclusive prefix inside
+// the segment, tot[seg] = segment sum.  zero != 0: the counts are cleared for the next rebuild.
+template <int BS>
+__device__ __forceinline__ void seg_scan(int* cnt, int nitem, int shift, int* loc, int* tot, bool zero) {
+  const int per = 1 << shift, nseg = (nitem + per - 1) >> shift;
+  for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
+    const int lo = seg << shift, hi = min(nitem, lo + per);
+    int carry = 0;
+    for (int base = lo; base < hi; base += BS) {
+      const int k = base + (int)threadIdx.x;
+      int v = 0;
+      if (k < hi) { v = cnt[k]; if (zero) cnt[k] = 0; }
+      int t;
+      const int ex = block_scan_excl<BS>(v, &t);
+      if (k < hi) loc[k] = carry + ex;
+      carry += t;
+    }
+    if (threadIdx.x == 0) tot[seg] = carry;
+  }
+}
+
+template <typename R, int BS>
+__global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
+  __shared__ TileLDS<R> T;
+  __shared__ int s_off[1025];
+  __shared__ unsigned long long s_m[BS / 64];
+  __shared__ int s_tile;
+  CHEM_DYN_LDS(R);
+  const int t = threadIdx.x, b = blockIdx.x, NB = gridDim.x, lane = lane_id(), w = t >> 6;
+  DevCtl* const ctl = a.ctl;
+
+  // ---- P0: decision, computed redundantly by every workgroup ----
+  unsigned long long m = 0;
+  for (int k = t; k < a.nblk; k += BS) { const unsigned long long v = a.blockmax[k]; m = v > m ? v : m; }
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(m, o); m = v > m ? v : m; }
+  if (lane == 0) s_m[w] = m;
+  __syncthreads();
+  m = s_m[0];
+#pragma unroll
+  for (int k = 1; k < BS / 64; ++k) m = s_m[k] > m ? s_m[k] : m;
+  const double m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
+  double acc = a.criterion ? sqrt(m2) : ctl->acc_pp[a.par] + sqrt(m2);
+  const int need = (acc > a.half_skin) || ctl->force_rebuild;
+  if (!need) {
+    if (b == 0 && t == 0) { ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = acc; ctl->acc_maxdist = acc; ctl->need_rebuild = 0; }
+    return;
+  }
+
+  // ---- P1: bin ----
+  if (b == 0 && t == 0) a.gb->stamp[0] = wall_clock64();
+  if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
+  { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl); }
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[1] = wall_clock64();
+  // every workgroup has taken its decision: the control block may change now
+  if (b == 0 && t == 0) {
+    ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = 0.0; ctl->acc_maxdist = 0.0; ctl->force_rebuild = 0;
+    ctl->rebuild_count++; ctl->need_rebuild = 1;
+  }
+
+  // ---- P2: cell counts -> per-segment exclusive prefixes + segment totals ----
+  seg_scan<BS>(a.cell_cnt, a.ncell, a.seg_shift, a.cell_loc, a.btot, true);
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[2] = wall_clock64();
+
+  // ---- P3: final cell_start of the own segments; particle -> sorted position ----
+  {
+    const int per = 1 << a.seg_shift, nseg = (a.ncell + per - 1) >> a.seg_shift;
+    seg_offsets<BS>(a.btot, nseg, s_off);
+    for (int seg = b; seg < nseg; seg += NB) {
+      const int lo = seg << a.seg_shift, hi = min(a.ncell, lo + per);
+      for (int c = lo + t; c < hi; c += BS) a.cell_start[c] = a.cell_loc[c] + s_off[seg];
+    }
+    if (b == 0 && t == 0) a.cell_start[a.ncell] = s_off[nseg];
+    for (int i = b * BS + t; i < a.n; i += NB * BS) {
+      const int c = a.cell_of[i];
+      if (c >= 0) a.perm[a.cell_loc[c] + s_off[c >> a.seg_shift] + a.slot_of[i]] = i;
+    }
+  }
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[3] = wall_clock64();
+
+  // ---- P4: canonical order inside every cell + gather; home-particle count of every tile ----
+  dev_sort_gather<R>(a.ncell, a.cell_start, a.perm, a.x4, a.v4, a.tag, a.img4, a.x4o, a.v4o, a.tago, a.img4o);
+  {
+    const int nx = a.box.nc[0], ny = a.box.nc[1], nz = a.box.nc[2];
+    const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
+    for (int tile = b * BS + t; tile < a.ntiles; tile += NB * BS) {
+      const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+      const int cx0 = tx * HX, cy0 = ty * HY, cz0 = tz * HZ;
+      const int hx = min(HX, nx - cx0), hy = min(HY, ny - cy0), hz = min(HZ, nz - cz0);
+      int nh = 0;
+      for (int hzi = 0; hzi < hz; ++hzi) for (int hyi = 0; hyi < hy; ++hyi) {
+        const int c0 = ((cz0 + hzi) * ny + (cy0 + hyi)) * nx + cx0;
+        nh += a.cell_start[c0 + hx] - a.cell_start[c0];
+      }
+      a.tn[tile] = nh;
+    }
+  }
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[4] = wall_clock64();
+
+  // ---- P5: copy back (+ tag -> index map, reference positions), tile descriptors, tile-count scan ----
+  for (int k = b * BS + t; k < a.n; k += NB * BS) {
+    const Vec4<R> xk = a.x4o[k];
+    a.x4[k] = xk; if (a.x0) a.x0[k] = xk;
+    a.v4[k] = a.v4o[k]; a.img4[k] = a.img4o[k];
+    const int tg = a.tago[k]; a.tag[k] = tg; a.rtag[tg] = k;
+  }
+  for (int tile = b; tile < a.ntiles; tile += NB) {
+    __syncthreads();
+    tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl);
+    const int* src = reinterpret_cast<const int*>(&T);
+    int* dst = reinterpret_cast<int*>(&a.desc[tile]);
+    for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
+  }
+  seg_scan<BS>(a.tn, a.ntiles, a.tseg_shift, a.tloc, a.tbtot, false);
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[5] = wall_clock64();
+
+  // ---- P6: list build; tiles are handed out dynamically, each XCD first drains its own contiguous
+  //          range of tiles (L2 locality, see xcd_remap) and then helps the others ----
+  {
+    const int tper = 1 << a.tseg_shift, ntseg = (a.ntiles + tper - 1) >> a.tseg_shift;
+    seg_offsets<BS>(a.tbtot, ntseg, s_off);
+    if (a.nbent > 0) dev_bonded_prep(0, a.n, a.tag, a.rtag, a.bstart, a.bent, a.bse, a.bj);   // rtag is complete since the last barrier
+    const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
+    for (;;) {
+      __syncthreads();
+      if (t == 0) {
+        int tile = -1;
+        for (int d = 0; d < 8 && tile < 0; ++d) {
+          const int x = (myx + d) & 7;
+          const int cntx = q + (x < r ? 1 : 0);
+          if (__hip_atomic_load(&a.gb->tq[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)cntx) continue;
+          const int k = (int)atomicAdd(&a.gb->tq[x][0], 1u);
+          if (k < cntx) tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+        }
+        s_tile = tile;
+      }
+      __syncthreads();
+      const int tile = s_tile;
+      if (tile < 0) break;
+      tile_load_desc<R>(T, a.desc, tile);
+      __syncthreads();
+      if (t == 0) { const int hb = a.tloc[tile] + s_off[tile >> a.tseg_shift]; T.geom[5] = hb; a.desc[tile].geom[5] = hb; }
+      tile_fill<R, BS, true>(T, sx, a.CAP, a.x4, 1);
+      __syncthreads();
+      dev_nlist_tile<R, BS>(T, sx, a.tag, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
+                            a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4);
+    }
+  }
+  if (b == 0 && t == 0) a.gb->stamp[6] = wall_clock64();
 }
 
 // =======================================================================================
