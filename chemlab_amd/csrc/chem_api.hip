@@ -121,7 +121,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
   // fused rebuild (single domain, tiles): segment scans + grid barrier state
   DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot; DBuf<GridBar> gbar;
-  DBuf<int2> bse; DBuf<int4> bj; bool bwork_dirty = true;   // bonded work list (see dev_bonded_prep)
+  DBuf<int4> bwork, bj; int nb_owner = 0; bool bwork_dirty = true;   // bonded work list (see dev_bonded_prep)
   int fused_grid = 0, fused_par = 0, seg_shift = 0, tseg_shift = 0; bool use_fused = false;
   DBuf<int> nlist, nn, nnh;
   DBuf<unsigned short> nl16;
@@ -259,7 +259,7 @@ template <typename R> struct CtxT : Ctx {
     a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
     a.desc = tdesc.p; a.excl_start = excl_start.p; a.excl_list = excl_list.p; a.nl16 = nl16.p; a.nnh = nnh.p; a.nlist = nlist.p; a.nn = nn.p;
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
-    a.bstart = bstart.p; a.bent = bent.p; a.bse = bse.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
+    a.bstart = bstart.p; a.bent = bent.p; a.bwork = bwork.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
     hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), tile_lds_bytes(), stream, a);
     fused_par ^= 1;
   }
@@ -435,7 +435,9 @@ template <typename R> struct CtxT : Ctx {
     if (!hp.empty()) HIPCHK(hipMemcpyAsync(bpar.p, hp.data(), hp.size() * sizeof(BondedParam), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
     nbent = (int64_t)he.size();
-    bse.alloc((size_t)std::max(acap(), 1)); bj.alloc(std::max<size_t>(he.size(), 1));
+    nb_owner = 0;
+    for (size_t t = 0; t + 1 < hs.size(); ++t) nb_owner += hs[t + 1] > hs[t] ? 1 : 0;
+    bwork.alloc(std::max(nb_owner, 1)); bj.alloc(std::max<size_t>(he.size(), 1));
     bwork_dirty = true;
     bonded_dirty = false;
   }
@@ -656,10 +658,11 @@ template <typename R> struct CtxT : Ctx {
     if (nbent > 0 && use_fused) {
       // work-list kernel: owners only, partner indices resolved at the last rebuild
       if (bwork_dirty) {   // bonded lists changed without a rebuild since
-        hipLaunchKernelGGL(k_bonded_prep, dim3(std::min(cdiv(n, 256), 2048)), dim3(256), 0, stream, 0, n, tag.p, rtag.p, bstart.p, bent.p, bse.p, bj.p);
+        HIPCHK(hipMemsetAsync(&ctl.p->bwork_count, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_bonded_prep, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, stream, 0, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
         bwork_dirty = false;
       }
-      hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(n, 256)), dim3(256), 0, stream, n, x4.p, f4.p, bse.p, bj.p, bent.p, bpar.p, boxd, ctl.p);
+      hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p);
     } else if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
                          bpar.p, boxd, elist.p, ctl.p);

@@ -58,7 +58,7 @@ struct DevCtl {
   int barrier_timeout;                // fused rebuild: a grid barrier gave up waiting (fatal)
   int pad0;
   double acc_pp[2];                   // fused rebuild: accumulated distance, double-buffered by launch parity
-  int bwork_count;                    // (unused)
+  int bwork_count;                    // particles in the bonded work list
   int excl_slot_error;                // list build: an excluded partner was not found in the cell computed from its position (internal)
 };
 
@@ -1416,34 +1416,63 @@ __global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __
   f4[i] = fo;
 }
 
+// exclusive scan over the block (BS threads, BS/64 <= 16 waves); returns the exclusive prefix of v,
+// *total = block sum.  Two barriers; safe to call back to back.
+template <int BS>
+__device__ __forceinline__ int block_scan_excl(int v, int* total) {
+  __shared__ int ws[16];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  __syncthreads();
+  if (lane == 63) ws[w] = incl;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < BS / 64; ++k) { if (k < w) off += ws[k]; tot += ws[k]; }
+  *total = tot;
+  return off + incl - v;
+}
+
 // ---- bonded work list: rebuilt together with the Verlet list (the particle order only changes
-// there).  bse[i] = entry range of the particle at index i, bj = the entries' partner tags already
-// resolved to particle indices.  The per-step kernel has one coalesced load in front of the early
-// exit and two dependent loads in front of the arithmetic instead of five.
+// there).  bwork = compact list of the particles that own bonded entries (i, e0, e1), bj = the
+// entries' partner tags already resolved to particle indices.  The per-step kernel runs over the
+// owners only, with full waves (the fp64 term code is long: a wave with one bonded lane costs as
+// much as a full one), and has two dependent loads in front of the arithmetic instead of five.
+template <int BS>
 __device__ __forceinline__ void dev_bonded_prep(int i0, int n, const int* tag, const int* rtag, const int* bstart, const BondedEntry* bent,
-                                                int2* bse, int4* bj) {
-  for (int i = i0 + blockIdx.x * blockDim.x + threadIdx.x; i < i0 + n; i += gridDim.x * blockDim.x) {
-    const int tg = tag[i];
-    const int e0 = bstart[tg], e1 = bstart[tg + 1];
-    bse[i] = make_int2(e0, e1);
+                                                int4* bwork, int4* bj, DevCtl* ctl) {
+  __shared__ int s_base;
+  const int iend = i0 + n;
+  for (int ib = i0 + blockIdx.x * BS; ib < iend; ib += gridDim.x * BS) {   // block-uniform bound (block scan below)
+    const int i = ib + threadIdx.x;
+    int e0 = 0, e1 = 0;
+    if (i < iend) { const int tg = tag[i]; e0 = bstart[tg]; e1 = bstart[tg + 1]; }
+    const int has = e1 > e0 ? 1 : 0;
+    int tot;
+    const int rank = block_scan_excl<BS>(has, &tot);       // one global atomic per block and pass, not per wave:
+    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&ctl->bwork_count, tot) : 0;   // same-address atomics cost ~12 ns each
+    __syncthreads();
+    if (has) bwork[s_base + rank] = make_int4(i, e0, e1, 0);
     for (int e = e0; e < e1; ++e) { const BondedEntry be = bent[e]; bj[e] = make_int4(rtag[be.t0], rtag[be.t1], rtag[be.t2], 0); }
+    __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* __restrict__ tag, const int* __restrict__ rtag, const int* __restrict__ bstart,
-                                                     const BondedEntry* __restrict__ bent, int2* __restrict__ bse, int4* __restrict__ bj) {
-  dev_bonded_prep(i0, n, tag, rtag, bstart, bent, bse, bj);
+                                                     const BondedEntry* __restrict__ bent, int4* __restrict__ bwork, int4* __restrict__ bj, DevCtl* ctl) {
+  dev_bonded_prep<256>(i0, n, tag, rtag, bstart, bent, bwork, bj, ctl);
 }
 
 template <typename R>
-__global__ __launch_bounds__(256) void k_bonded_work(int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int2* __restrict__ bse, const int4* __restrict__ bj,
+__global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int4* __restrict__ bwork, const int4* __restrict__ bj,
                                                      const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int2 se = bse[i];
-  if (se.x == se.y) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ctl->bwork_count) return;
+  const int4 wk = bwork[k];
   D3 f = {0, 0, 0};
-  for (int e = se.x; e < se.y; ++e) {
+  for (int e = wk.y; e < wk.z; ++e) {
     const int meta = bent[e].meta;
     const int4 jj = bj[e];
     const int slot = meta & 0x0fffffff, me = (meta >> 28) & 3;
@@ -1452,9 +1481,9 @@ __global__ __launch_bounds__(256) void k_bonded_work(int n, const Vec4<R>* __res
     if (bp.arity == 4) { j3 = bj[e + 1].x; ++e; }
     bonded_term<R, false>(bp, me, jj.x, jj.y, bp.arity > 2 ? jj.z : 0, j3, x4, box, f, nullptr, ctl);
   }
-  Vec4<R> fo = f4[i];
+  Vec4<R> fo = f4[wk.x];
   fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;
-  f4[i] = fo;
+  f4[wk.x] = fo;
 }
 
 // =======================================================================================
@@ -1511,25 +1540,6 @@ __device__ __forceinline__ bool grid_barrier(GridBar* gb, DevCtl* ctl) {
   return ok_s != 0;
 }
 
-// exclusive scan over the block (BS threads, BS/64 <= 16 waves); returns the exclusive prefix of v,
-// *total = block sum.  Two barriers; safe to call back to back.
-template <int BS>
-__device__ __forceinline__ int block_scan_excl(int v, int* total) {
-  __shared__ int ws[16];
-  const int lane = lane_id(), w = threadIdx.x >> 6;
-  int incl = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-  __syncthreads();
-  if (lane == 63) ws[w] = incl;
-  __syncthreads();
-  int off = 0, tot = 0;
-#pragma unroll
-  for (int k = 0; k < BS / 64; ++k) { if (k < w) off += ws[k]; tot += ws[k]; }
-  *total = tot;
-  return off + incl - v;
-}
-
 template <typename R> struct FusedArgs {
   int n, ncell, ntiles, CAP, S, has_excl, criterion, par, seg_shift, tseg_shift, nblk, want32;
   double half_skin; R rl2;
@@ -1539,7 +1549,7 @@ template <typename R> struct FusedArgs {
   TileLDS<R>* desc; const int *excl_start, *excl_list;
   unsigned short* nl16; int *nnh, *nlist, *nn;
   unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
-  const int* bstart; const BondedEntry* bent; int2* bse; int4* bj; int nbent;
+  const int* bstart; const BondedEntry* bent; int4 *bwork, *bj; int nbent;
   Box<R> box; ActMask act;
 };
 
@@ -1610,6 +1620,7 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
   // ---- P1: bin ----
   if (b == 0 && t == 0) a.gb->stamp[0] = wall_clock64();
   if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
+  if (b == 0 && t == 8) ctl->bwork_count = 0;
   { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl); }
   if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[1] = wall_clock64();
   // every workgroup has taken its decision: the control block may change now
@@ -1679,7 +1690,7 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
   {
     const int tper = 1 << a.tseg_shift, ntseg = (a.ntiles + tper - 1) >> a.tseg_shift;
     seg_offsets<BS>(a.tbtot, ntseg, s_off);
-    if (a.nbent > 0) dev_bonded_prep(0, a.n, a.tag, a.rtag, a.bstart, a.bent, a.bse, a.bj);   // rtag is complete since the last barrier
+    if (a.nbent > 0) dev_bonded_prep<BS>(0, a.n, a.tag, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl);   // rtag is complete since the last barrier
     const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
     for (;;) {
       __syncthreads();
