@@ -11,6 +11,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
+#include <thread>
+#include <exception>
 #include <tuple>
 
 #include "chem_comm.hpp"
@@ -104,6 +106,7 @@ struct Ctx {
   virtual void set_pair_bs(int) {}
   virtual int64_t debug_dump(long long*, int64_t) { return 0; }
   virtual void debug_enable(int) {}
+  virtual void join_async() {}
 };
 
 template <typename R> struct CtxT : Ctx {
@@ -128,6 +131,19 @@ template <typename R> struct CtxT : Ctx {
   DBuf<TileLDS<R>> tdesc;
   DBuf<long long> dbgbuf; bool dbg_on = false;
   Candidate* pin_ev = nullptr; size_t pin_ev_cap = 0;   // pinned host staging for reaction events
+  // cluster labels of a reaction step are merged on a host thread beside the following MD steps;
+  // joined (and uploaded) before the next reaction scan and before any other API call
+  std::thread label_thr; bool labels_pending = false; std::exception_ptr label_err;
+  std::vector<std::pair<int32_t, int32_t>> label_bonds; std::vector<int32_t> label_touched;
+  void join_async() override {
+    if (label_thr.joinable()) label_thr.join();
+    if (label_err) { std::exception_ptr e = label_err; label_err = nullptr; labels_pending = false; std::rethrow_exception(e); }
+    if (labels_pending) {
+      res_id.upload(top.res_id, stream); mol_id.upload(top.mol_id, stream);
+      HIPCHK(hipStreamSynchronize(stream));
+      labels_pending = false;
+    }
+  }
   // ---- slab decomposition state: reals live at [G, G+n), lower ghosts right-aligned in front of
   // them, upper ghosts behind; cap = allocated particles
   int nglob = 0, lower = 0, upper = 0, nzg = 0, z0 = 0, ncz = 0;
@@ -163,6 +179,7 @@ template <typename R> struct CtxT : Ctx {
 
   CtxT() { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
   ~CtxT() override {
+    if (label_thr.joinable()) label_thr.join();
     if (stream) (void)hipStreamSynchronize(stream);   // nothing may still write the pinned words or the buffers
     tr.reset();
     for (auto e : ev) (void)hipEventDestroy(e);
@@ -428,6 +445,9 @@ template <typename R> struct CtxT : Ctx {
   void upload_bonded() {
     std::vector<int32_t> hs; std::vector<HBondedEntry> he; std::vector<HBondedParam> hp;
     top.build_bonded(hs, he, hp);
+    upload_bonded_from(hs, he, hp);
+  }
+  void upload_bonded_from(const std::vector<int32_t>& hs, const std::vector<HBondedEntry>& he, const std::vector<HBondedParam>& hp) {
     static_assert(sizeof(HBondedEntry) == sizeof(BondedEntry) && sizeof(HBondedParam) == sizeof(BondedParam), "layout");
     bstart.alloc(hs.size()); bent.alloc(he.size()); bpar.alloc(hp.size());
     HIPCHK(hipMemcpyAsync(bstart.p, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -620,7 +640,7 @@ template <typename R> struct CtxT : Ctx {
   // ---- forces -------------------------------------------------------------------------
   int pick_tpp() const {
     if (opt_tpp > 0) return use_tiles ? std::min(opt_tpp, 8) : opt_tpp;
-    if (use_tiles) return 2;
+    if (use_tiles) return ntiles >= 768 ? 1 : 2;   // one lane per home particle once the tiles alone fill the chip (3 workgroups x 256 CUs)
     return n >= 100000 ? 4 : (n >= 8000 ? 8 : 16);
   }
 
@@ -747,6 +767,12 @@ template <typename R> struct CtxT : Ctx {
       while (ev.size() < want) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev.push_back(e); }
       ev_used = 0;
     }
+    if (react_on && !reactions.empty() && pin_ev_cap == 0) {
+      // pinned staging for the event download: at most one event per two particles; allocated here so
+      // that the first reaction step does not pay ~10 ms for it
+      pin_ev_cap = (size_t)top.n / 2 + 1024;
+      HIPCHK(hipHostMalloc((void**)&pin_ev, pin_ev_cap * sizeof(Candidate), hipHostMallocDefault));
+    }
     if (resort) rebuild_now();
     compute_forces();
     if (lang) launch_integrate<0>(true, true, step, 0);  // thermalize: f += friction + noise, stored
@@ -791,6 +817,7 @@ template <typename R> struct CtxT : Ctx {
     const double t0 = now_s();
     tm.reaction_steps++;
     if (reactions.empty()) return;
+    join_async();   // labels of the previous reaction step must be on the device before the scan
     if (cand_cap == 0) {
       cand_cap = std::max(8 * nglob, 1024);
       cand.alloc(cand_cap); evout.alloc(cand_cap); st0.alloc(cand_cap); st1.alloc(cand_cap);
@@ -891,7 +918,23 @@ template <typename R> struct CtxT : Ctx {
     auto ekey = [](const Candidate& p) { return ((uint64_t)(uint32_t)std::min(p.a, p.b) << 32) | (uint32_t)std::max(p.a, p.b); };
     {
       auto mid = std::partition(hev.begin(), hev.end(), [&](const Candidate& p) { return !reactions[p.r].is_virtual; });
-      std::sort(hev.begin(), mid, [&](const Candidate& p, const Candidate& q) { return ekey(p) < ekey(q); });
+      // A particle takes part in at most one event per reaction step, so min(a,b) alone is a unique
+      // key: LSD radix sort (3 x 11 bits) instead of a comparison sort of 10^5 events.
+      const size_t m = (size_t)(mid - hev.begin());
+      std::vector<Candidate> tmp(m);
+      Candidate* src = hev.data(); Candidate* dst = tmp.data();
+      for (int pass = 0; pass < 3; ++pass) {
+        size_t cnt[2049] = {0};
+        const int sh = 11 * pass;
+        for (size_t k = 0; k < m; ++k) ++cnt[(((uint32_t)std::min(src[k].a, src[k].b) >> sh) & 2047u) + 1];
+        for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+        for (size_t k = 0; k < m; ++k) dst[cnt[((uint32_t)std::min(src[k].a, src[k].b) >> sh) & 2047u]++] = src[k];
+        std::swap(src, dst);
+      }
+      if (src != hev.data()) std::copy(src, src + m, hev.data());
+      bool unique = true;
+      for (size_t k = 1; k < m && unique; ++k) unique = std::min(hev[k - 1].a, hev[k - 1].b) != std::min(hev[k].a, hev[k].b);
+      if (!unique) std::sort(hev.begin(), mid, [&](const Candidate& p, const Candidate& q) { return ekey(p) < ekey(q); });
     }
     std::vector<std::pair<int32_t, int32_t>> newbonds;
     bool types_changed = false;
@@ -913,13 +956,41 @@ template <typename R> struct CtxT : Ctx {
       }
     }
     state_mirror_stale = true;
+    if (g_trace) fprintf(stderr, "[chem trace] events %zu new bonds %zu\n", hev.size(), newbonds.size());
     trc.lap("host events");
     if (!newbonds.empty()) {
-      std::vector<int32_t> touched;
-      top.on_new_bonds(newbonds, touched);
-      trc.lap("on_new_bonds");
-      res_id.upload(top.res_id, stream); mol_id.upload(top.mol_id, stream);
-      upload_bonded(); trc.lap("upload_bonded"); upload_excl(); trc.lap("upload_excl");
+      // Host work of a bond-forming step, arranged by what depends on what:
+      //   bonded CSR  <- lists            exclusion CSR <- exclusions <- (spawned tuples <- graph)
+      //   cluster labels <- graph, read again only by the NEXT reaction scan -> host thread, joined lazily
+      label_bonds = newbonds; label_touched.clear(); labels_pending = true;
+      std::vector<int32_t> hs; std::vector<HBondedEntry> he; std::vector<HBondedParam> hp;
+      std::vector<int32_t> es, el;
+      if (!top.spawns_tuples()) {
+        std::thread tb([&] { top.build_bonded(hs, he, hp); });
+        label_thr = std::thread([this] {
+          try { top.link_new_bonds(label_bonds); top.merge_new_bonds(label_bonds, label_touched); } catch (...) { label_err = std::current_exception(); }
+        });
+        top.exclude_new_bonds(newbonds);
+        trc.lap("exclude");
+        top.build_excl(es, el);
+        trc.lap("build_excl");
+        tb.join();
+      } else {
+        top.link_new_bonds(newbonds);
+        label_thr = std::thread([this] {
+          try { top.merge_new_bonds(label_bonds, label_touched); } catch (...) { label_err = std::current_exception(); }
+        });
+        top.spawn_for_new_bonds(newbonds);
+        trc.lap("link+spawn");
+        std::thread tx([&] { top.build_excl(es, el); });
+        top.build_bonded(hs, he, hp);
+        tx.join();
+      }
+      upload_bonded_from(hs, he, hp);
+      excl_start.upload(es, stream); excl_list.upload(el, stream);
+      HIPCHK(hipStreamSynchronize(stream));
+      has_excl = el.empty() ? 0 : 1; excl_dirty = false;
+      trc.lap("uploads");
       resort = true;
       set_ctl_field(&DevCtl::force_rebuild, 1);
     }
@@ -1109,7 +1180,8 @@ using namespace chem;
 struct chem_ctx { std::unique_ptr<Ctx> c; };
 
 #define CTX (*ctx->c)
-#define API_BEGIN try {
+#define API_BEGIN try { if (ctx && ctx->c) ctx->c->join_async();
+#define API_BEGIN_NOJOIN try {
 #define API_END(ctxp)                                                                  \
   } catch (const ChemError& e) { (ctxp)->c->err = e.what(); return e.code; }           \
     catch (const std::exception& e) { (ctxp)->c->err = e.what(); return CHEM_EINVAL; }
@@ -1361,7 +1433,7 @@ int chem_reaction_set_rate(chem_ctx* ctx, int r, double rate) {
 }
 
 int chem_run(chem_ctx* ctx, int64_t nsteps) {
-  API_BEGIN
+  API_BEGIN_NOJOIN   // a pending label merge keeps running beside the MD steps; react_step joins it
   REQUIRE(nsteps >= 0, CHEM_EINVAL, "nsteps");
   CTX.run(nsteps);
   return 0;

@@ -189,9 +189,33 @@ struct HostTopology {
   }
 
   // TopologyManager reaction to freshly created bonds (canonical order = given order)
+  // The reaction to new bonds has two independent halves: the cluster labels (res_id / mol_id, read
+  // again only by the NEXT reaction scan) and the lists/exclusions (needed by the very next force
+  // evaluation).  on_new_bonds = both, in the reference's order; the engine calls the halves
+  // separately so that the label flood fills can run beside the following MD steps.
   void on_new_bonds(const std::vector<std::pair<int32_t, int32_t>>& nb, std::vector<int32_t>& touched) {
-    for (auto& e : nb) graph_add(e.first, e.second);
+    link_new_bonds(nb);
+    merge_new_bonds(nb, touched);
+    spawn_for_new_bonds(nb);
+  }
+  void link_new_bonds(const std::vector<std::pair<int32_t, int32_t>>& nb) {
+    for (size_t k = 0; k < nb.size(); ++k) {
+      if (k + 8 < nb.size()) { __builtin_prefetch(&graph[nb[k + 8].first]); __builtin_prefetch(&graph[nb[k + 8].second]); }
+      graph_add(nb[k].first, nb[k].second);
+    }
+  }
+  bool spawns_tuples() const { for (auto& l : lists) if (!l.registered.empty()) return true; return false; }
+  // exclusions of the new bonds only (no registered angle/dihedral types: nothing else to spawn)
+  void exclude_new_bonds(const std::vector<std::pair<int32_t, int32_t>>& nb) {
+    for (size_t k = 0; k < nb.size(); ++k) {
+      if (k + 8 < nb.size()) { __builtin_prefetch(&excl[nb[k + 8].first]); __builtin_prefetch(&excl[nb[k + 8].second]); }
+      exclude(nb[k].first, nb[k].second);
+    }
+  }
+  void merge_new_bonds(const std::vector<std::pair<int32_t, int32_t>>& nb, std::vector<int32_t>& touched) {
     for (auto& e : nb) merge_cluster(e.first, e.second, true, touched);
+  }
+  void spawn_for_new_bonds(const std::vector<std::pair<int32_t, int32_t>>& nb) {
     bool any3 = false, any4 = false;
     for (auto& l : lists) { if (!l.registered.empty()) { any3 |= l.arity == 3; any4 |= l.arity == 4; } }
     for (auto& e : nb) {
