@@ -938,22 +938,33 @@ template <typename R> struct CtxT : Ctx {
     }
     std::vector<std::pair<int32_t, int32_t>> newbonds;
     bool types_changed = false;
-    {
+    // event log + host mirrors of the new types (only what the host itself needs later: types for
+    // bonded-slot resolution and the topology manager; chemical states live on the device).  Events
+    // touch disjoint particles, nothing below reads the mirrors unless a list is typed or tuples are
+    // spawned, so this runs beside the table builds and is joined at the end of the step.
+    auto log_and_mirror = [&] {
       Ctx::RawEvents blk; blk.step = step;
       blk.a.resize(hev.size()); blk.b.resize(hev.size()); blk.r.resize(hev.size()); blk.d2.resize(hev.size());
       for (size_t k = 0; k < hev.size(); ++k) { blk.a[k] = hev[k].a; blk.b[k] = hev[k].b; blk.r[k] = hev[k].r; blk.d2[k] = hev[k].d2; }
       raw_events.push_back(std::move(blk)); n_events += (int64_t)hev.size();
-    }
+      for (auto& e : hev) {
+        const chem_reaction_desc& d = reactions[e.r];
+        if (d.new_type_1 >= 0 && d.new_type_1 != top.type[e.a]) { top.type[e.a] = d.new_type_1; top.mass[e.a] = d.new_mass_1; top.q[e.a] = d.new_q_1; types_changed = true; }
+        if (d.new_type_2 >= 0 && d.new_type_2 != top.type[e.b]) { top.type[e.b] = d.new_type_2; top.mass[e.b] = d.new_mass_2; top.q[e.b] = d.new_q_2; types_changed = true; }
+      }
+    };
+    bool mirrors_first = top.spawns_tuples();
+    for (auto& l : top.lists) mirrors_first |= l.by_types != 0;
+    std::thread mirror_thr;
+    std::exception_ptr mirror_err;
+    if (mirrors_first) log_and_mirror();
+    else mirror_thr = std::thread([&] { try { log_and_mirror(); } catch (...) { mirror_err = std::current_exception(); } });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } mirror_join{mirror_thr};   // also on the error paths
     for (auto& e : hev) {
       const chem_reaction_desc& d = reactions[e.r];
-      // host mirrors: only what the host itself needs later (types for bonded-slot resolution and
-      // the topology manager); chemical states live on the device
-      if (d.new_type_1 >= 0 && d.new_type_1 != top.type[e.a]) { top.type[e.a] = d.new_type_1; top.mass[e.a] = d.new_mass_1; top.q[e.a] = d.new_q_1; types_changed = true; }
-      if (d.new_type_2 >= 0 && d.new_type_2 != top.type[e.b]) { top.type[e.b] = d.new_type_2; top.mass[e.b] = d.new_mass_2; top.q[e.b] = d.new_q_2; types_changed = true; }
-      if (!d.is_virtual) {
-        int32_t t[2] = {e.a, e.b};
-        if (top.list_insert(top.lists[d.bond_list], t)) newbonds.emplace_back(e.a, e.b);
-      }
+      if (d.is_virtual) break;   // bond-forming events were partitioned to the front
+      int32_t t[2] = {e.a, e.b};
+      if (top.list_insert(top.lists[d.bond_list], t)) newbonds.emplace_back(e.a, e.b);
     }
     state_mirror_stale = true;
     if (g_trace) fprintf(stderr, "[chem trace] events %zu new bonds %zu\n", hev.size(), newbonds.size());
@@ -994,6 +1005,8 @@ template <typename R> struct CtxT : Ctx {
       resort = true;
       set_ctl_field(&DevCtl::force_rebuild, 1);
     }
+    if (mirror_thr.joinable()) mirror_thr.join();
+    if (mirror_err) std::rethrow_exception(mirror_err);
     if (types_changed) { resort = true; set_ctl_field(&DevCtl::force_rebuild, 1); }   // force list depends on types
     if (newbonds.empty() && types_changed) {
       bool any_typed = false;
