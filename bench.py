@@ -115,8 +115,17 @@ def main():
         nb = tm["nlist_entries"] / float(a.n)
         bytes_per_particle = 36.0 + 4.0 * nb      # B_force = 16 (x_i) + 4<nb> + 4 (count) + 16 (f4)
         achieved = a.n * bytes_per_particle / avg_s
-        out["roofline"] = dict(bound="hbm", kernel="k_pair_force", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                               frac=achieved / HBM_PEAK, traffic=None, avg_launch_us=avg_s * 1e6, launches=launches,
+        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py):
+        # 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE, see tools/pmc_traffic.py
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pair_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("particles") == a.n:
+                traffic = tj.get("traffic_bytes_per_launch")
+        out["roofline"] = dict(bound="hbm", kernel="k_pair_tiles", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                               frac=achieved / HBM_PEAK, traffic=traffic, avg_launch_us=avg_s * 1e6, launches=launches,
                                mean_neighbours=nb, algorithmic_bytes_per_particle=bytes_per_particle,
                                whole_step_frac=a.n * (bytes_per_particle + 80.0) * steps_per_s / HBM_PEAK)
     if a.verbose:
