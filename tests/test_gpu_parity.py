@@ -231,6 +231,42 @@ def test_reactive_trajectory_event_log_identical_fp64(make_gpu, make_oracle):
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
 
 
+@pytest.mark.parametrize("prec", [32, 64])
+def test_fused_rebuild_equals_unfused_chain_bitwise(make_gpu, prec):
+    """One persistent rebuild launch (grid barriers, tile queues, bonded work list, exclusions located
+    as tile slots) against the chain of separate kernels it replaces (exclusions by tag): the list a
+    particle gets does not depend on which workgroup built it or how exclusions were filtered, so the
+    two trajectories -- Langevin noise, reactions, new bonds and exclusions included -- are bit-identical."""
+    spec = W.reactive_melt(n=8788, seed=21, interval=20)
+    a, b = make_gpu(prec), make_gpu(prec)
+    for e in (a, b):
+        W.apply(spec, e)
+    b.set_option("fused_rebuild", 0)
+    for _ in range(4):
+        a.run(20); b.run(20)
+    assert len(a.get_events()) > 1000
+    assert a.timers()["rebuilds"] == b.timers()["rebuilds"] > 4
+    assert sorted_events(a.get_events()) == sorted_events(b.get_events())
+    assert np.array_equal(a.get_exclusions(), b.get_exclusions())
+    for what in ("POS", "VEL", "FORCE", "STATE", "TYPE", "RESID", "MOLID"):
+        assert np.array_equal(a.get_state(what), b.get_state(what)), what
+    assert np.array_equal(a.get_verlet_pairs(), b.get_verlet_pairs())
+
+
+def test_fused_rebuild_many_exclusions_per_particle(make_gpu, make_oracle):
+    """Chains with bonds, angles and dihedrals: inner monomers carry 6 exclusions (> the 4 slots of
+    the in-tile exclusion path), chain ends fewer -- both routes inside one list build, against the oracle."""
+    spec = W.polymer_melt(n_chains=400, chain_len=24, seed=8)
+    g, o, _ = both(make_gpu, make_oracle, spec, 64, thermostat=False)
+    g.run(0); o.run(0)
+    assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-10
+    g.run(40); o.run(40)
+    assert g.timers()["rebuilds"] > 3
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+    assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
+
+
 def test_random_partner_mode_and_partial_rate_identical(make_gpu, make_oracle):
     spec = W.reactive_melt(n=4000, seed=13, interval=10, rate=20.0)     # p = 20*0.005*10 = 1.0 -> use 6.0 -> 0.3
     for r in spec["reaction"]["reactions"]:
