@@ -584,6 +584,7 @@ template <typename R> struct CtxT : Ctx {
     // 7. tiles + lists over the own layers
     launch_list_chain();
     set_ctl_field(&DevCtl::need_rebuild, 0);
+    bwork_dirty = true;   // particle order and ghosts changed: the bonded work list is rebuilt before the next force evaluation
     ++dd_rebuilds;
   }
 
@@ -675,11 +676,11 @@ template <typename R> struct CtxT : Ctx {
     if (timed) HIPCHK(hipEventRecord(ev[ev_used], stream));
     launch_pair<false>(f4.p, tpp);
     if (timed) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; }
-    if (nbent > 0 && use_fused) {
+    if (nbent > 0 && (use_fused || dd_on)) {
       // work-list kernel: owners only, partner indices resolved at the last rebuild
       if (bwork_dirty) {   // bonded lists changed without a rebuild since
         HIPCHK(hipMemsetAsync(&ctl.p->bwork_count, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(k_bonded_prep, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, stream, 0, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
+        hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
         bwork_dirty = false;
       }
       hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p);
