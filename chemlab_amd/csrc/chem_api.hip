@@ -88,6 +88,7 @@ struct Ctx {
   int opt_fuse = 1;         // fused integrate2+integrate1
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
   int opt_fused = 1;        // rebuild chain as one persistent launch with grid barriers (single domain, tiles)
+  int pair_guard = 0;       // 256 while the force kernels are launched speculatively (decomposed path)
   int opt_criterion = 0;     // 1: rebuild when max |x - x(last build)| > skin/2 ; 0: reference's accumulated per-step maxima
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
@@ -525,6 +526,36 @@ template <typename R> struct CtxT : Ctx {
   }
 
   // ---- slab decomposition ---------------------------------------------------------------
+  void ensure_hflag() {
+    if (hflag) return;
+    HIPCHK(hipHostMalloc((void**)&hflag, 4096, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(hflag, 0, 4096);
+    HIPCHK(hipHostGetDevicePointer((void**)&hflag_dev, hflag, 0));
+    dd_vals.alloc(64);
+  }
+  void poll_ticket(volatile int* word, int ticket, const char* what) {
+    long long spins = 0;
+    while (*word != ticket) {
+      if ((++spins & 0xfffff) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {   // stream drained or failed: re-check once, then give up
+        if (*word == ticket) break;
+        HIPCHK(hipStreamSynchronize(stream));
+        if (*word != ticket) throw ChemError(CHEM_EDEVICE, std::string(what) + " never arrived from the device");
+      }
+    }
+  }
+  // up to 8 device integers with one poll instead of one blocking copy each
+  int collect_ticket = 0;
+  void collect_ints(std::initializer_list<const int*> src, int* out) {
+    ensure_hflag();
+    CollectArgs a{}; a.n = 0;
+    for (const int* p : src) a.src[a.n++] = p;
+    const int ticket = ++collect_ticket;
+    hipLaunchKernelGGL(k_collect_ints, dim3(1), dim3(64), 0, stream, a, (volatile int*)(hflag_dev + 16), ticket);
+    poll_ticket(hflag + 16, ticket, "slab rebuild counters");
+    for (int k = 0; k < a.n; ++k) out[k] = hflag[17 + k];
+  }
+  void set_need_rebuild_async(int v) { HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&ctl.p->need_rebuild, v, 1, stream)); }
+
   int read_int(const int* dev) {
     int v = 0;
     HIPCHK(hipMemcpyAsync(&v, dev, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -537,13 +568,15 @@ template <typename R> struct CtxT : Ctx {
   // cells/tiles/lists.  Every rank enters together (the trigger is a cross-rank maximum).
   void rebuild_dd() {
     const int nxy = box.nc[0] * box.nc[1];
-    set_ctl_field(&DevCtl::need_rebuild, 1);
+    set_need_rebuild_async(1);
     // 1. bin the reals; leavers go to the migration buffers
     HIPCHK(hipMemsetAsync(mig[0].p, 0, 16, stream)); HIPCHK(hipMemsetAsync(mig[1].p, 0, 16, stream));
     launch_sort_chain(G, n);
     // 2. migration exchange (fixed-capacity buffers, count in the header)
     tr->exchange(mig[0].p, mig_bytes(), mig[1].p, mig_bytes(), mig[2].p, mig_bytes(), mig[3].p, mig_bytes(), lower, upper, stream);
-    const int from_up = read_int(reinterpret_cast<int*>(mig[2].p)), from_lo = read_int(reinterpret_cast<int*>(mig[3].p));
+    int cnt2[2];
+    collect_ints({reinterpret_cast<const int*>(mig[2].p), reinterpret_cast<const int*>(mig[3].p)}, cnt2);
+    const int from_up = cnt2[0], from_lo = cnt2[1];
     if (from_up > mcap || from_lo > mcap) throw ChemError(CHEM_ENOSPC, "domain decomposition: migration buffer overflow");
     if (G + n + from_lo + from_up > cap - G) throw ChemError(CHEM_ENOSPC, "domain decomposition: slab capacity exceeded by arrivals");
     // 3. arrivals behind the current reals, then bin them too (they are in their own slab now)
@@ -566,12 +599,14 @@ template <typename R> struct CtxT : Ctx {
     hipLaunchKernelGGL(k_layer_counts, dim3(cdiv(nxy + 1, 256)), dim3(256), 0, stream, nxy, ncz, cell_start.p, lcnt_dn.p, lcnt_up.p);
     tr->exchange(lcnt_dn.p, (nxy + 1) * sizeof(int), lcnt_up.p, (nxy + 1) * sizeof(int), gcnt_up.p, (nxy + 1) * sizeof(int), gcnt_lo.p,
                  (nxy + 1) * sizeof(int), lower, upper, stream);
-    n = read_int(cell_start.p + (size_t)(ncz + 1) * nxy) - G;
-    if (read_int(reinterpret_cast<int*>(mig[0].p)) || read_int(reinterpret_cast<int*>(mig[1].p)))
-      throw ChemError(CHEM_ESTATE, "domain decomposition: a migrated particle left its new slab immediately");
-    halo_dn_off = G; halo_dn_cnt = read_int(lcnt_dn.p + nxy);
-    halo_up_cnt = read_int(lcnt_up.p + nxy); halo_up_off = G + n - halo_up_cnt;
-    nglo = read_int(gcnt_lo.p + nxy); ngup = read_int(gcnt_up.p + nxy);
+    int c7[7];
+    collect_ints({cell_start.p + (size_t)(ncz + 1) * nxy, reinterpret_cast<const int*>(mig[0].p), reinterpret_cast<const int*>(mig[1].p),
+                  lcnt_dn.p + nxy, lcnt_up.p + nxy, gcnt_lo.p + nxy, gcnt_up.p + nxy}, c7);
+    n = c7[0] - G;
+    if (c7[1] || c7[2]) throw ChemError(CHEM_ESTATE, "domain decomposition: a migrated particle left its new slab immediately");
+    halo_dn_off = G; halo_dn_cnt = c7[3];
+    halo_up_cnt = c7[4]; halo_up_off = G + n - halo_up_cnt;
+    nglo = c7[5]; ngup = c7[6];
     if (nglo > G || G + n + ngup > cap) throw ChemError(CHEM_ENOSPC, "domain decomposition: ghost layer exceeds the reserved capacity");
     // 6. ghost particles: contiguous slices, received in place (lower ghosts right-aligned in front of the reals)
     tr->exchange(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
@@ -583,7 +618,7 @@ template <typename R> struct CtxT : Ctx {
     if (ngup) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(ngup, 256)), dim3(256), 0, stream, G + n, ngup, tag.p, rtag.p);
     // 7. tiles + lists over the own layers
     launch_list_chain();
-    set_ctl_field(&DevCtl::need_rebuild, 0);
+    set_need_rebuild_async(0);
     bwork_dirty = true;   // particle order and ghosts changed: the bonded work list is rebuilt before the next force evaluation
     ++dd_rebuilds;
   }
@@ -649,7 +684,7 @@ template <typename R> struct CtxT : Ctx {
     const double hs = 0.5 * skin;
     if (use_tiles) {
 #define LT(T, M, B) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M>), dim3(ntiles), dim3(B), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, fdst, tdesc.p, \
-                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr)
+                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, opt_ablate | pair_guard, dbg_on ? dbgbuf.p : (long long*)nullptr)
 #define LTB(T, M) do { if (pair_bs == 256) LT(T, M, 256); else if (pair_bs == 512) LT(T, M, 512); else LT(T, M, 1024); } while (0)
 #define LTT(M) do { switch (tpp) { case 1: LTB(1, M); break; case 2: LTB(2, M); break; case 8: LTB(8, M); break; default: LTB(4, M); break; } } while (0)
       const int mode = ENERGY ? 0 : (uniform_lj ? 2 : (lj_only ? 1 : 0));
@@ -670,7 +705,8 @@ template <typename R> struct CtxT : Ctx {
     return nb;
   }
 
-  void compute_forces() {
+  void compute_forces(bool speculative = false) {
+    pair_guard = speculative ? 256 : 0;
     const int tpp = pick_tpp();
     const bool timed = opt_time_pair && ev_used + 2 <= ev.size();
     if (timed) HIPCHK(hipEventRecord(ev[ev_used], stream));
@@ -683,10 +719,11 @@ template <typename R> struct CtxT : Ctx {
         hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
         bwork_dirty = false;
       }
-      hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p);
+      hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0);
     } else if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
                          bpar.p, boxd, elist.p, ctl.p);
+    pair_guard = 0;
   }
 
   LangevinP<R> lang_params(int64_t istep, int phase) const {
@@ -729,12 +766,7 @@ template <typename R> struct CtxT : Ctx {
   // position update (posted before the decision is known: it is needed unless we rebuild), and the
   // collective rebuild when the trigger fired.  One host synchronisation per step.
   void dd_step_sync() {
-    if (!hflag) {
-      HIPCHK(hipHostMalloc((void**)&hflag, 4096, hipHostMallocMapped | hipHostMallocCoherent));
-      hflag[0] = hflag[1] = 0;
-      HIPCHK(hipHostGetDevicePointer((void**)&hflag_dev, hflag, 0));
-      dd_vals.alloc(64);
-    }
+    ensure_hflag();
     // local fold -> ctl->step_m2; its all-to-all rides in the halo exchange group; decision from the
     // P gathered values, mirrored into pinned host memory so that the host learns it by polling one
     // word (no memcpy, no stream synchronisation call)
@@ -745,17 +777,14 @@ template <typename R> struct CtxT : Ctx {
     const int ticket = ++hticket;
     hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, 0, 0.5 * skin, opt_criterion, 2,
                        dd_vals.p, P, (volatile int*)hflag_dev, ticket);
-    if (getenv("CHEM_DD_NOPOLL")) { DevCtl hc = read_ctl(); if (hc.need_rebuild) rebuild_dd(); return; }
+    // The force kernels are enqueued BEFORE the host looks at the decision: they leave at once when a
+    // rebuild is pending (then the host rebuilds and launches them again), otherwise the device never
+    // waits for the host's poll + launch latency.
+    compute_forces(true);
+    if (getenv("CHEM_DD_NOPOLL")) { DevCtl hc = read_ctl(); if (hc.need_rebuild) { rebuild_dd(); compute_forces(); } return; }
     volatile int* hf = hflag;
-    long long spins = 0;
-    while (hf[1] != ticket) {
-      if ((++spins & 0xfffff) == 0 && hipStreamQuery(stream) != hipErrorNotReady) {   // stream drained or failed: re-check once, then give up
-        if (hf[1] == ticket) break;
-        HIPCHK(hipStreamSynchronize(stream));
-        if (hf[1] != ticket) throw ChemError(CHEM_EDEVICE, "rebuild decision never arrived from the device");
-      }
-    }
-    if (hf[0]) rebuild_dd();
+    poll_ticket(hflag + 1, ticket, "rebuild decision");
+    if (hf[0]) { rebuild_dd(); compute_forces(); }
   }
 
   // ---- the hot call -------------------------------------------------------------------
@@ -780,8 +809,8 @@ template <typename R> struct CtxT : Ctx {
     bool need_int1 = true;
     for (int64_t s = 0; s < nsteps; ++s) {
       if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
-      if (dd_on) dd_step_sync(); else decide_and_rebuild();
-      compute_forces();
+      if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
+      else { decide_and_rebuild(); compute_forces(); }
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
       const bool last = (s == nsteps - 1);
       if (last || react_due || !opt_fuse) {

@@ -195,6 +195,16 @@ __global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned l
   }
 }
 
+// a handful of device integers to pinned host memory with ONE poll on the host (the slab rebuild
+// used to read them with one blocking copy each): host[0] = ticket (written last), host[1..n] = values
+struct CollectArgs { const int* src[8]; int n; };
+__global__ void k_collect_ints(CollectArgs a, volatile int* host, int ticket) {
+  if ((int)threadIdx.x < a.n) host[1 + threadIdx.x] = *a.src[threadIdx.x];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) host[0] = ticket;
+}
+
 // =======================================================================================
 // K1  cell binning + canonical sort (storage.decompose(), start_simulation.py:158-171)
 // =======================================================================================
@@ -1208,6 +1218,8 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
   if (dbg) st0 = wall_clock64();
   if (ablate == 4) return;   // diagnostic: dispatch cost only
+  if ((ablate & 256) && ctl->need_rebuild) return;   // speculative launch (decomposed path): the host rebuilds first and launches again
+  ablate &= 255;
   __shared__ TileLDS<R> T;
   __shared__ PairCore<R> spc[kMaxTypes * kMaxTypes];
   CHEM_DYN_LDS(R);
@@ -1467,9 +1479,9 @@ __global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* _
 
 template <typename R>
 __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int4* __restrict__ bwork, const int4* __restrict__ bj,
-                                                     const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl) {
+                                                     const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl, int guard) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= ctl->bwork_count) return;
+  if (k >= ctl->bwork_count || (guard && ctl->need_rebuild)) return;
   const int4 wk = bwork[k];
   D3 f = {0, 0, 0};
   for (int e = wk.y; e < wk.z; ++e) {
