@@ -32,6 +32,20 @@ static double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// std::vector storage in pinned host memory: the device tables rebuilt at reaction steps (bonded and
+// exclusion CSR, ~14 MB at 10^6 particles) are uploaded at PCIe speed instead of through the
+// pageable-copy bounce buffers (2.5 ms -> 0.5 ms)
+template <typename T> struct PinnedAlloc {
+  using value_type = T;
+  PinnedAlloc() = default;
+  template <class U> PinnedAlloc(const PinnedAlloc<U>&) {}
+  T* allocate(size_t n) { void* p = nullptr; if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocDefault) != hipSuccess) throw std::bad_alloc(); return (T*)p; }
+  void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+  template <class U> bool operator==(const PinnedAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const PinnedAlloc<U>&) const { return false; }
+};
+template <typename T> using PinnedVec = std::vector<T, PinnedAlloc<T>>;
+
 template <typename T> struct DBuf {
   T* p = nullptr; size_t n = 0;
   void alloc(size_t count) {
@@ -42,7 +56,7 @@ template <typename T> struct DBuf {
   }
   void free() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
   ~DBuf() { free(); }
-  void upload(const std::vector<T>& h, hipStream_t s) {
+  template <class V> void upload(const V& h, hipStream_t s) {
     alloc(h.size());
     if (!h.empty()) HIPCHK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   }
@@ -135,6 +149,7 @@ template <typename R> struct CtxT : Ctx {
   // cluster labels of a reaction step are merged on a host thread beside the following MD steps;
   // joined (and uploaded) before the next reaction scan and before any other API call
   std::thread label_thr; bool labels_pending = false; std::exception_ptr label_err;
+  PinnedVec<int32_t> stage_hs, stage_es, stage_el; PinnedVec<HBondedEntry> stage_he; std::vector<HBondedParam> stage_hp;   // host staging of the device tables, reused
   std::vector<std::pair<int32_t, int32_t>> label_bonds; std::vector<int32_t> label_touched;
   void join_async() override {
     if (label_thr.joinable()) label_thr.join();
@@ -448,7 +463,7 @@ template <typename R> struct CtxT : Ctx {
     top.build_bonded(hs, he, hp);
     upload_bonded_from(hs, he, hp);
   }
-  void upload_bonded_from(const std::vector<int32_t>& hs, const std::vector<HBondedEntry>& he, const std::vector<HBondedParam>& hp) {
+  template <class VI, class VE> void upload_bonded_from(const VI& hs, const VE& he, const std::vector<HBondedParam>& hp) {
     static_assert(sizeof(HBondedEntry) == sizeof(BondedEntry) && sizeof(HBondedParam) == sizeof(BondedParam), "layout");
     bstart.alloc(hs.size()); bent.alloc(he.size()); bpar.alloc(hp.size());
     HIPCHK(hipMemcpyAsync(bstart.p, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -802,6 +817,10 @@ template <typename R> struct CtxT : Ctx {
       // that the first reaction step does not pay ~10 ms for it
       pin_ev_cap = (size_t)top.n / 2 + 1024;
       HIPCHK(hipHostMalloc((void**)&pin_ev, pin_ev_cap * sizeof(Candidate), hipHostMallocDefault));
+      // pinned staging of the tables a bond-forming step rebuilds; sized so that growing them (a
+      // pinned reallocation costs milliseconds) is rare: one entry per particle to start with
+      stage_hs.reserve((size_t)top.n + 1); stage_es.reserve((size_t)top.n + 1);
+      stage_he.reserve((size_t)top.n); stage_el.reserve((size_t)top.n);
     }
     if (resort) rebuild_now();
     compute_forces();
@@ -1004,10 +1023,10 @@ template <typename R> struct CtxT : Ctx {
       //   bonded CSR  <- lists            exclusion CSR <- exclusions <- (spawned tuples <- graph)
       //   cluster labels <- graph, read again only by the NEXT reaction scan -> host thread, joined lazily
       label_bonds = newbonds; label_touched.clear(); labels_pending = true;
-      std::vector<int32_t> hs; std::vector<HBondedEntry> he; std::vector<HBondedParam> hp;
-      std::vector<int32_t> es, el;
+      auto& hs = stage_hs; auto& he = stage_he; auto& hp = stage_hp;
+      auto& es = stage_es; auto& el = stage_el;
       if (!top.spawns_tuples()) {
-        std::thread tb([&] { top.build_bonded(hs, he, hp); });
+        std::thread tb([&] { const double tb0 = now_s(); top.build_bonded(hs, he, hp); if (g_trace) fprintf(stderr, "[chem trace] build_bonded (thread) %.3f ms\n", 1e3 * (now_s() - tb0)); });
         label_thr = std::thread([this] {
           try { top.link_new_bonds(label_bonds); top.merge_new_bonds(label_bonds, label_touched); } catch (...) { label_err = std::current_exception(); }
         });
@@ -1016,6 +1035,7 @@ template <typename R> struct CtxT : Ctx {
         top.build_excl(es, el);
         trc.lap("build_excl");
         tb.join();
+        trc.lap("join bonded");
       } else {
         top.link_new_bonds(newbonds);
         label_thr = std::thread([this] {

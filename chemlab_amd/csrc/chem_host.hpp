@@ -238,7 +238,9 @@ struct HostTopology {
 
   // ---- device tables ------------------------------------------------------------------
   // Parameter slots: one per plain list, one per (typed list, type tuple).
-  void build_bonded(std::vector<int32_t>& bstart, std::vector<HBondedEntry>& bent, std::vector<HBondedParam>& bpar) const {
+  mutable std::vector<int32_t> fill_scratch;   // reused between calls (fresh 4 MB vectors cost their page faults every time)
+  template <class VI, class VE>
+  void build_bonded(VI& bstart, VE& bent, std::vector<HBondedParam>& bpar) const {
     bpar.clear();
     std::vector<int> plain_slot(lists.size(), -1);
     std::vector<std::map<std::array<int, 4>, int>> typed_slot(lists.size());
@@ -278,29 +280,40 @@ struct HostTopology {
       }
     }
     for (int64_t t = 0; t < n; ++t) bstart[t + 1] += bstart[t];
-    bent.assign((size_t)bstart[n], HBondedEntry{0, 0, 0, 0});
-    std::vector<int32_t> fill(bstart.begin(), bstart.end() - 1);
+    if ((size_t)bstart[n] > bent.capacity()) bent.reserve((size_t)bstart[n] * 2);   // (pinned storage: reallocation is expensive)
+    bent.resize((size_t)bstart[n]);
+    fill_scratch.assign(bstart.begin(), bstart.end() - 1);
+    std::vector<int32_t>& fill = fill_scratch;
     for (size_t li = 0; li < lists.size(); ++li) {
       const HostList& l = lists[li];
       for (size_t e = 0; e + l.arity <= l.ent.size(); e += l.arity) {
-        const int32_t* t = &l.ent[e];
-        const int slot = slot_of(li, t);
+        const int32_t* tt = &l.ent[e];
+        const int slot = slot_of(li, tt);
         if (slot < 0) continue;
         for (int k = 0; k < l.arity; ++k) {
-          int32_t& pos = fill[t[k]];
-          HBondedEntry be{t[0], t[1], l.arity > 2 ? t[2] : 0, slot | (k << 28)};
-          bent[pos++] = be;
-          if (l.arity == 4) bent[pos++] = HBondedEntry{t[3], 0, 0, 0};
+          int32_t& pos = fill[tt[k]];
+          bent[pos++] = HBondedEntry{tt[0], tt[1], l.arity > 2 ? tt[2] : 0, slot | (k << 28)};
+          if (l.arity == 4) bent[pos++] = HBondedEntry{tt[3], 0, 0, 0};
         }
       }
     }
   }
 
-  void build_excl(std::vector<int32_t>& estart, std::vector<int32_t>& elist) const {
-    estart.assign((size_t)n + 1, 0);
-    for (int64_t t = 0; t < n; ++t) estart[t + 1] = estart[t] + (int32_t)excl[t].size();
-    elist.resize((size_t)estart[n]);
-    for (int64_t t = 0; t < n; ++t) std::copy(excl[t].begin(), excl[t].end(), elist.begin() + estart[t]);
+  template <class VI>
+  void build_excl(VI& estart, VI& elist) const {
+    // one pass over the rows (40 B each, 10^6 of them: the pass itself is the cost); the symmetric
+    // table has exactly 2 entries per excluded pair
+    estart.resize((size_t)n + 1);
+    if ((size_t)(2 * n_excl_pairs) > elist.capacity()) elist.reserve((size_t)(4 * n_excl_pairs));
+    elist.resize((size_t)(2 * n_excl_pairs));
+    int32_t pos = 0;
+    for (int64_t t = 0; t < n; ++t) {
+      estart[t] = pos;
+      const TagRow& r = excl[t];
+      if (r.n) { if (pos + r.n > (int64_t)elist.size()) elist.resize((size_t)pos + r.n + 1024); std::copy(r.begin(), r.end(), elist.begin() + pos); pos += r.n; }
+    }
+    estart[n] = pos;
+    elist.resize((size_t)pos);
   }
 };
 
