@@ -86,11 +86,16 @@ def main():
     eng.run(a.warmup)
     eng.sync()
     ev0 = len(eng.get_events())
+    if not a.no_roofline:
+        # dominant per-step kernel = pair force: HIP events on the launch stream around every 8th launch
+        # of the TIMED region (the list grows while bonds form, so a sample after the run would be biased)
+        eng.set_option("time_pair_kernel", 8)
     t0 = time.perf_counter()
     eng.run(a.steps)
     eng.sync()
     wall = time.perf_counter() - t0
     tm = eng.timers()
+    eng.set_option("time_pair_kernel", 0)
     nev = len(eng.get_events()) - ev0
     steps_per_s = a.steps / wall
 
@@ -104,13 +109,7 @@ def main():
                            tau_per_day=steps_per_s * spec["dt"] * 86400, parallelism="1 GPU, single domain"))
 
     if not a.no_roofline:
-        # dominant kernel = pair force; HIP events on the launch stream around every launch
-        eng.set_option("time_pair_kernel", 1)
-        nprof = min(200, max(a.steps, 10))
-        eng.run(nprof)
-        tm = eng.timers()
-        eng.set_option("time_pair_kernel", 0)
-        launches = tm["pair_kernel_launches"]
+        launches = tm["pair_kernel_launches"]          # of the last run() = the timed region
         avg_s = 1e-3 * tm["pair_kernel_ms"] / max(launches, 1)
         nb = tm["nlist_entries"] / float(a.n)
         bytes_per_particle = 36.0 + 4.0 * nb      # B_force = 16 (x_i) + 4<nb> + 4 (count) + 16 (f4)

@@ -98,7 +98,8 @@ struct Ctx {
   bool geom_dirty = true, particles_dirty = true, pair_dirty = true, bonded_dirty = true, excl_dirty = true, labels_dirty = true;
   int nl_capacity_user = 0;
   int opt_tpp = 0;          // 0 = automatic
-  int opt_time_pair = 0;    // HIP-event timing of every pair-force launch
+  int opt_time_pair = 0;    // HIP-event timing of every N-th pair-force launch (0 = off)
+  int64_t pair_launch_no = 0;
   int opt_fuse = 1;         // fused integrate2+integrate1
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
   int opt_fused = 1;        // rebuild chain as one persistent launch with grid barriers (single domain, tiles)
@@ -723,7 +724,7 @@ template <typename R> struct CtxT : Ctx {
   void compute_forces(bool speculative = false) {
     pair_guard = speculative ? 256 : 0;
     const int tpp = pick_tpp();
-    const bool timed = opt_time_pair && ev_used + 2 <= ev.size();
+    const bool timed = opt_time_pair && !speculative && (pair_launch_no++ % opt_time_pair) == 0 && ev_used + 2 <= ev.size();
     if (timed) HIPCHK(hipEventRecord(ev[ev_used], stream));
     launch_pair<false>(f4.p, tpp);
     if (timed) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; }
@@ -1565,7 +1566,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   API_BEGIN
   const std::string k = name ? name : "";
   if (k == "tpp") { const int v = (int)value; REQUIRE(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64, CHEM_EINVAL, "tpp must be a power of two <= 64"); CTX.opt_tpp = v; }
-  else if (k == "time_pair_kernel") CTX.opt_time_pair = value != 0;
+  else if (k == "time_pair_kernel") CTX.opt_time_pair = value > 0 ? (int)value : 0;
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else if (k == "fused_rebuild") { CTX.opt_fused = value != 0; CTX.geom_dirty = true; }
