@@ -583,6 +583,7 @@ template <typename R> struct CtxT : Ctx {
   // exchange the boundary layers as ghosts (contiguous slices of the cell-sorted arrays), rebuild
   // cells/tiles/lists.  Every rank enters together (the trigger is a cross-rank maximum).
   void rebuild_dd() {
+    Trace trd("dd");
     const int nxy = box.nc[0] * box.nc[1];
     set_need_rebuild_async(1);
     // 1. bin the reals; leavers go to the migration buffers
@@ -593,6 +594,7 @@ template <typename R> struct CtxT : Ctx {
     int cnt2[2];
     collect_ints({reinterpret_cast<const int*>(mig[2].p), reinterpret_cast<const int*>(mig[3].p)}, cnt2);
     const int from_up = cnt2[0], from_lo = cnt2[1];
+    trd.lap("bin+migrate+poll");
     if (from_up > mcap || from_lo > mcap) throw ChemError(CHEM_ENOSPC, "domain decomposition: migration buffer overflow");
     if (G + n + from_lo + from_up > cap - G) throw ChemError(CHEM_ENOSPC, "domain decomposition: slab capacity exceeded by arrivals");
     // 3. arrivals behind the current reals, then bin them too (they are in their own slab now)
@@ -618,6 +620,7 @@ template <typename R> struct CtxT : Ctx {
     int c7[7];
     collect_ints({cell_start.p + (size_t)(ncz + 1) * nxy, reinterpret_cast<const int*>(mig[0].p), reinterpret_cast<const int*>(mig[1].p),
                   lcnt_dn.p + nxy, lcnt_up.p + nxy, gcnt_lo.p + nxy, gcnt_up.p + nxy}, c7);
+    trd.lap("sort+counts+poll");
     n = c7[0] - G;
     if (c7[1] || c7[2]) throw ChemError(CHEM_ESTATE, "domain decomposition: a migrated particle left its new slab immediately");
     halo_dn_off = G; halo_dn_cnt = c7[3];
@@ -625,16 +628,17 @@ template <typename R> struct CtxT : Ctx {
     nglo = c7[5]; ngup = c7[6];
     if (nglo > G || G + n + ngup > cap) throw ChemError(CHEM_ENOSPC, "domain decomposition: ghost layer exceeds the reserved capacity");
     // 6. ghost particles: contiguous slices, received in place (lower ghosts right-aligned in front of the reals)
-    tr->exchange(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
-                 x4.p + G - nglo, nglo * sizeof(V4), lower, upper, stream);
-    tr->exchange(tag.p + halo_dn_off, halo_dn_cnt * sizeof(int), tag.p + halo_up_off, halo_up_cnt * sizeof(int), tag.p + G + n, ngup * sizeof(int),
-                 tag.p + G - nglo, nglo * sizeof(int), lower, upper, stream);
+    tr->exchange2(Transport::Msg{x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
+                                 x4.p + G - nglo, nglo * sizeof(V4)},
+                  Transport::Msg{tag.p + halo_dn_off, halo_dn_cnt * sizeof(int), tag.p + halo_up_off, halo_up_cnt * sizeof(int), tag.p + G + n, ngup * sizeof(int),
+                                 tag.p + G - nglo, nglo * sizeof(int)}, lower, upper, stream);
     hipLaunchKernelGGL(k_ghost_cells, dim3(1), dim3(1024), 0, stream, nxy, ncz, gcnt_lo.p, gcnt_up.p, cell_start.p);
     if (nglo) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(nglo, 256)), dim3(256), 0, stream, G - nglo, nglo, tag.p, rtag.p);
     if (ngup) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(ngup, 256)), dim3(256), 0, stream, G + n, ngup, tag.p, rtag.p);
     // 7. tiles + lists over the own layers
     launch_list_chain();
     set_need_rebuild_async(0);
+    if (g_trace) { HIPCHK(hipStreamSynchronize(stream)); trd.lap("ghosts+tiles+list"); }
     bwork_dirty = true;   // particle order and ghosts changed: the bonded work list is rebuilt before the next force evaluation
     ++dd_rebuilds;
   }

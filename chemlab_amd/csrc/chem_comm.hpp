@@ -32,6 +32,12 @@ struct Transport {
   // Byte counts; all four may differ.  Enqueued on `s`.
   virtual void exchange(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
                         void* from_lo, size_t from_lo_bytes, int lower, int upper, hipStream_t s) = 0;
+  // Two exchanges with the same neighbours in one communication phase (ghost positions + ghost tags).
+  struct Msg { const void* dn; size_t dn_bytes; const void* up; size_t up_bytes; void* from_up; size_t from_up_bytes; void* from_lo; size_t from_lo_bytes; };
+  virtual void exchange2(const Msg& a, const Msg& b, int lower, int upper, hipStream_t s) {
+    exchange(a.dn, a.dn_bytes, a.up, a.up_bytes, a.from_up, a.from_up_bytes, a.from_lo, a.from_lo_bytes, lower, upper, s);
+    exchange(b.dn, b.dn_bytes, b.up, b.up_bytes, b.from_up, b.from_up_bytes, b.from_lo, b.from_lo_bytes, lower, upper, s);
+  }
   // The same exchange plus, in the same communication phase, every rank's `my` value delivered to
   // slot [rank] of every other rank's `all` array (the step's displacement maximum: the list-rebuild
   // decision needs the global max, and a separate all-reduce would cost a second launch + latency).
@@ -122,6 +128,19 @@ struct RcclTransport : Transport {
     ck(a.Send(up, up_bytes, RcclApi::kInt8, upper, comm, s), "ncclSend");
     ck(a.Recv(from_up, from_up_bytes, RcclApi::kInt8, upper, comm, s), "ncclRecv");
     ck(a.Recv(from_lo, from_lo_bytes, RcclApi::kInt8, lower, comm, s), "ncclRecv");
+    ck(a.GroupEnd(), "ncclGroupEnd");
+  }
+  void exchange2(const Msg& m1, const Msg& m2, int lower, int upper, hipStream_t s) override {
+    RcclApi& a = rccl_api();
+    ck(a.GroupStart(), "ncclGroupStart");          // same pairing rule as exchange(): k-th send to a peer <-> its k-th receive from us
+    for (const Msg* m : {&m1, &m2}) {
+      ck(a.Send(m->dn, m->dn_bytes, RcclApi::kInt8, lower, comm, s), "ncclSend");
+      ck(a.Send(m->up, m->up_bytes, RcclApi::kInt8, upper, comm, s), "ncclSend");
+    }
+    for (const Msg* m : {&m1, &m2}) {
+      ck(a.Recv(m->from_up, m->from_up_bytes, RcclApi::kInt8, upper, comm, s), "ncclRecv");
+      ck(a.Recv(m->from_lo, m->from_lo_bytes, RcclApi::kInt8, lower, comm, s), "ncclRecv");
+    }
     ck(a.GroupEnd(), "ncclGroupEnd");
   }
   void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
