@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
                                                    int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
                                                    double half_skin, DevCtl* ctl, int ablate, long long* __restrict__ dbg) {
   constexpr bool LJONLY = MODE >= 1;
-  constexpr int NCH = TPP == 1 ? 5 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
+  constexpr int NCH = TPP == 1 ? 3 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
   if (dbg) st0 = wall_clock64();
   if (ablate == 4) return;   // diagnostic: dispatch cost only
