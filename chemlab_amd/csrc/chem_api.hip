@@ -822,6 +822,14 @@ template <typename R> struct CtxT : Ctx {
       // that the first reaction step does not pay ~10 ms for it
       pin_ev_cap = (size_t)top.n / 2 + 1024;
       HIPCHK(hipHostMalloc((void**)&pin_ev, pin_ev_cap * sizeof(Candidate), hipHostMallocDefault));
+      {  // the first copy-engine transfer out of a fresh device allocation into a fresh pinned range costs ~7 ms
+         // (mappings): pay it here, not in the first reaction step
+        alloc_reaction_buffers();
+        const size_t bytes = std::min(pin_ev_cap, (size_t)cand_cap) * sizeof(Candidate);
+        HIPCHK(hipMemsetAsync(evout.p, 0, bytes, stream));
+        HIPCHK(hipMemcpyAsync(pin_ev, evout.p, bytes, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+      }
       // pinned staging of the tables a bond-forming step rebuilds; sized so that growing them (a
       // pinned reallocation costs milliseconds) is rare: one entry per particle to start with
       stage_hs.reserve((size_t)top.n + 1); stage_es.reserve((size_t)top.n + 1);
@@ -867,17 +875,19 @@ template <typename R> struct CtxT : Ctx {
   }
 
   // ---- reactions ----------------------------------------------------------------------
+  void alloc_reaction_buffers() {
+    if (cand_cap != 0) return;
+    cand_cap = std::max(8 * nglob, 1024);
+    cand.alloc(cand_cap); evout.alloc(cand_cap); st0.alloc(cand_cap); st1.alloc(cand_cap);
+    asA.alloc(nglob); asB.alloc(nglob); best1.alloc(nglob); best2.alloc(nglob); evcount.alloc(1); rs_dev.alloc(1);
+    if (dd_on) { cand_loc.alloc((size_t)cand_cap); cnt_all.alloc(64); }
+  }
   void react_step() {
     const double t0 = now_s();
     tm.reaction_steps++;
     if (reactions.empty()) return;
     join_async();   // labels of the previous reaction step must be on the device before the scan
-    if (cand_cap == 0) {
-      cand_cap = std::max(8 * nglob, 1024);
-      cand.alloc(cand_cap); evout.alloc(cand_cap); st0.alloc(cand_cap); st1.alloc(cand_cap);
-      asA.alloc(nglob); asB.alloc(nglob); best1.alloc(nglob); best2.alloc(nglob); evcount.alloc(1); rs_dev.alloc(1);
-      if (dd_on) { cand_loc.alloc((size_t)cand_cap); cnt_all.alloc(64); }
-    }
+    alloc_reaction_buffers();
     ReactSet rs{};
     rs.n = (int)reactions.size(); rs.seed = react_seed; rs.step = (uint64_t)step; rs.nearest = nearest;
     ReactApplySet ras{};
@@ -957,15 +967,20 @@ template <typename R> struct CtxT : Ctx {
     int nev = 0;
     HIPCHK(hipMemcpyAsync(&nev, evcount.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    trc.lap("resolve+apply");
     if ((size_t)nev > pin_ev_cap) {
       if (pin_ev) (void)hipHostFree(pin_ev);
       pin_ev_cap = std::max<size_t>((size_t)nev * 2, 1 << 16);
       HIPCHK(hipHostMalloc((void**)&pin_ev, pin_ev_cap * sizeof(Candidate), hipHostMallocDefault));
     }
-    if (nev) HIPCHK(hipMemcpyAsync(pin_ev, evout.p, (size_t)nev * sizeof(Candidate), hipMemcpyDeviceToHost, stream));
+    if (nev) {
+      const size_t n16 = ((size_t)nev * sizeof(Candidate) + 15) / 16;   // evout/pin_ev are sized in whole candidates (24 B): rounding up stays inside
+      hipLaunchKernelGGL(k_copy16, dim3(512), dim3(256), 0, stream, reinterpret_cast<const uint4*>(evout.p), reinterpret_cast<uint4*>(pin_ev), n16);
+    }
     HIPCHK(hipStreamSynchronize(stream));
+    trc.lap("download");
     std::vector<Candidate> hev(pin_ev, pin_ev + nev);
-    trc.lap("resolve+apply+download");
+    trc.lap("copy");
     // Host mirrors + topology.  Only bond-forming events need the canonical order now (it fixes
     // the order of the bond lists); the event log itself is put in canonical order lazily
     // by chem_get_events.

@@ -195,6 +195,12 @@ __global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned l
   }
 }
 
+// device -> pinned host memory by a kernel (16-byte stores over PCIe): the copy engine's first
+// transfer after a large allocation burst took 7 ms for 8 MB here
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t k = blockIdx.x * (size_t)blockDim.x + threadIdx.x; k < n16; k += (size_t)gridDim.x * blockDim.x) dst[k] = src[k];
+}
+
 // a handful of device integers to pinned host memory with ONE poll on the host (the slab rebuild
 // used to read them with one blocking copy each): host[0] = ticket (written last), host[1..n] = values
 struct CollectArgs { const int* src[8]; int n; };
