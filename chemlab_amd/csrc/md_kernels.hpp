@@ -1814,6 +1814,10 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
     }
     if (!any) cnt = 0;
   }
+  float maxcut2f = 0;
+  for (int q = 0; q < rs.n; ++q) if (rs.r[q].active) maxcut2f = fmaxf(maxcut2f, (float)rs.r[q].cut2);
+  maxcut2f *= 1.001f;
+  const float bLf[3] = {(float)box.L[0], (float)box.L[1], (float)box.L[2]}, biLf[3] = {(float)box.invL[0], (float)box.invL[1], (float)box.invL[2]};
   // uniform trip count inside a wave so that __ballot is convergent
   int maxcnt = cnt;
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(maxcnt, o); maxcnt = t > maxcnt ? t : maxcnt; }
@@ -1825,7 +1829,16 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
     if (live) {
       j = row[k]; tgj = tag[j];
       live = tgi < tgj;
-      if (live) { xj = x4[j]; tj = (int)xj.w; sj = state[tgj]; rj = res_id[tgj]; mj = mol_id[tgj]; }
+      if (live) {
+        xj = x4[j];
+        // cheap reject before the three by-tag gathers and the fp64 arithmetic: the reaction radii are
+        // far inside the list radius (1.2 vs 2.8: 8 % of the neighbours).  Same inputs as the fp64
+        // distance below, 1e-3 relative margin >> any rounding difference.
+        const float fx = (float)xi.x - (float)xj.x, fy = (float)xi.y - (float)xj.y, fz = (float)xi.z - (float)xj.z;
+        const float gx = fx - bLf[0] * rintf(fx * biLf[0]), gy = fy - bLf[1] * rintf(fy * biLf[1]), gz = fz - bLf[2] * rintf(fz * biLf[2]);
+        live = gx * gx + gy * gy + gz * gz <= maxcut2f;
+      }
+      if (live) { tj = (int)xj.w; sj = state[tgj]; rj = res_id[tgj]; mj = mol_id[tgj]; }
     }
     double d2 = 0;
     if (__any(live)) {
