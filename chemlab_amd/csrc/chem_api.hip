@@ -140,6 +140,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
   // fused rebuild (single domain, tiles): segment scans + grid barrier state
   DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot; DBuf<GridBar> gbar;
+  DBuf<int> tile_cnt, tile_off;   // reaction scan on tiles: candidates per tile, their offsets
   DBuf<int4> bwork, bj; int nb_owner = 0; bool bwork_dirty = true;   // bonded work list (see dev_bonded_prep)
   int fused_grid = 0, fused_par = 0, seg_shift = 0, tseg_shift = 0; bool use_fused = false;
   DBuf<int> nlist, nn, nnh;
@@ -302,6 +303,7 @@ template <typename R> struct CtxT : Ctx {
     const int bytes = (int)tile_lds_bytes();
 #define SETA(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
     SETA((k_nlist_tiles<R, 512>));
+    SETA((k_react_scan_tiles<R, 512>));
 #define SETB(T, E, M) SETA((k_pair_tiles<R, T, E, 256, M>)); SETA((k_pair_tiles<R, T, E, 512, M>)); SETA((k_pair_tiles<R, T, E, 1024, M>))
 #define SETT(E, M) SETB(1, E, M); SETB(2, E, M); SETB(4, E, M); SETB(8, E, M)
     SETT(false, 2); SETT(false, 1); SETT(false, 0); SETT(true, 0);
@@ -843,6 +845,8 @@ template <typename R> struct CtxT : Ctx {
       if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
       if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
       else { decide_and_rebuild(); compute_forces(); }
+      resort = false;   // a rebuild requested by the last reaction step (force_rebuild on the device) has happened by now
+
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
       const bool last = (s == nsteps - 1);
       if (last || react_due || !opt_fuse) {
@@ -903,11 +907,23 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipMemcpyAsync(rs_dev.p, &rs, sizeof(ReactSet), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
     Trace trc("react");
-    ensure_list32();
-    trc.lap("list32");
-    set_ctl_field(&DevCtl::cand_count, 0);
-    hipLaunchKernelGGL(k_react_scan<R>, dim3(cdiv((long long)n * 8, 256)), dim3(256), 0, stream, G, n, x4.p, tag.p, nlist.p, nn.p, S, state.p,
-                       res_id.p, mol_id.p, boxd, rs_dev.p, dd_on ? cand_loc.p : cand.p, cand_cap, ctl.p);
+    // No rebuild here: the particle order must not change between the force evaluation of this step and
+    // the first kick of the next one (forces are not re-sorted), and on the decomposed path a rebuild
+    // would migrate particles away from their forces.  Tiles: scan the staged stencils of the last
+    // rebuild (see k_react_scan_tiles).  Per-cell / brute-force lists: the int32 list is always current.
+    Candidate* cdst = dd_on ? cand_loc.p : cand.p;
+    if (use_tiles) {
+      const int region_cap = std::max(1, cand_cap / std::max(ntiles, 1));
+      tile_cnt.alloc(ntiles + 1); tile_off.alloc(ntiles + 1);
+      hipLaunchKernelGGL((k_react_scan_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, state.p,
+                         res_id.p, mol_id.p, boxd, rs_dev.p, evout.p, region_cap, tile_cnt.p, ctl.p);
+      hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, stream, ntiles, tile_cnt.p, tile_off.p, ctl.p);
+      hipLaunchKernelGGL(k_cand_gather, dim3(std::min(ntiles, 2048)), dim3(256), 0, stream, ntiles, evout.p, region_cap, tile_cnt.p, tile_off.p, cdst, cand_cap, ctl.p);
+    } else {
+      HIPCHK(hipMemsetAsync(&ctl.p->cand_count, 0, sizeof(int), stream));
+      hipLaunchKernelGGL(k_react_scan<R>, dim3(cdiv((long long)n * 8, 256)), dim3(256), 0, stream, G, n, x4.p, tag.p, nlist.p, nn.p, S, state.p,
+                         res_id.p, mol_id.p, boxd, rs_dev.p, cdst, cand_cap, ctl.p);
+    }
     DevCtl h = read_ctl();
     trc.lap("scan");
     if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
@@ -1165,7 +1181,7 @@ template <typename R> struct CtxT : Ctx {
 
   void observe(chem_obs* out) override {
     flush_host_state();
-    if (resort) rebuild_now();
+    if (resort) { rebuild_now(); compute_forces(); }   // a rebuild re-sorts the particles but not f4: keep it aligned for get_state(FORCE)
     std::memset(out, 0, sizeof(*out));
     const int tpp = pick_tpp();
     const int nb = launch_pair<true>(x4o.p, tpp);  // scratch force buffer: leaves f4 untouched
@@ -1196,6 +1212,7 @@ template <typename R> struct CtxT : Ctx {
   int64_t verlet_pairs(int64_t* out, int64_t cap) override {
     flush_host_state();
     ensure_list32();
+    compute_forces();   // the rebuild re-sorted the particles but not f4: keep it aligned for get_state(FORCE)
     const int ac = acap();
     std::vector<int> hn, ht, hl;
     nn.download(hn, ac, stream); tag.download(ht, ac, stream); nlist.download(hl, (size_t)ac * S, stream);

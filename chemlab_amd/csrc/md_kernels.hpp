@@ -1890,6 +1890,143 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
   }
 }
 
+// ---- reaction scan on the staged tiles, WITHOUT rebuilding anything.
+// The int32-list scan above needs a fresh list, i.e. a forced rebuild at the reaction step -- and a
+// rebuild re-sorts the particles but not their forces, which the next half-kick still needs (the
+// reaction sits between the force evaluation of step s and the first kick of step s+1).  This
+// kernel needs no list: two particles within a reaction radius (<= rc) now were within
+// radius + skin <= rc + skin = one cell edge at the last rebuild, so the 27-cell stencil of the
+// tile tables of THAT rebuild still contains every candidate, with the current positions staged
+// into LDS.  Per home particle: fp32 pre-test of the stencil candidates against the largest
+// reaction radius, then for the few survivors (tag order, states, labels) the fp64 distance from
+// the global arrays exactly as k_react_scan computes it, the reaction filters and the Philox draw.
+// Output: every tile appends to its own fixed region of `region` through an LDS counter (no
+// contended global atomic); k_cand_offsets / k_cand_gather compact the regions afterwards.
+template <typename R, int BS>
+__global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+                                                            const TileLDS<R>* __restrict__ desc, const int* __restrict__ state,
+                                                            const int* __restrict__ res_id, const int* __restrict__ mol_id, BoxD box,
+                                                            const ReactSet* __restrict__ rs_g, Candidate* __restrict__ region, int region_cap,
+                                                            int* __restrict__ tile_count, DevCtl* ctl) {
+  __shared__ TileLDS<R> T;
+  __shared__ ReactSet rs;
+  __shared__ int s_cnt;
+  CHEM_DYN_LDS(R);
+  {
+    const int* src = reinterpret_cast<const int*>(rs_g);
+    int* dst = reinterpret_cast<int*>(&rs);
+    for (int k = threadIdx.x; k < (int)(sizeof(ReactSet) / 4); k += BS) dst[k] = src[k];
+  }
+  __syncthreads();
+  R maxcut2 = 0;
+  for (int q = 0; q < rs.n; ++q) if (rs.r[q].active) maxcut2 = rs.r[q].cut2 > (double)maxcut2 ? (R)rs.r[q].cut2 : maxcut2;
+  maxcut2 *= (R)1.001;   // the staged positions carry the periodic shift: one more rounding than the global ones
+  for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
+    const int tile = xcd_remap(vb, ntiles);
+    __syncthreads();
+    tile_load_desc<R>(T, desc, tile);
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
+    __syncthreads();
+    const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4];
+    Candidate* out = region + (size_t)tile * region_cap;
+    for (int q = threadIdx.x; q < nhome; q += BS) {
+      int sgi = 0;
+#pragma unroll
+      for (int k = 1; k < NHSEG; ++k) sgi += (q >= T.hoff[k]) ? 1 : 0;
+      const int inrun = q - T.hoff[sgi];
+      const int p = T.hstart[sgi] + inrun;
+      const int ly = sgi % HY, lz = sgi / HY;
+      const int hr = (lz + 1) * SY + (ly + 1);
+      const int eh = inrun + T.celloff[hr][1];
+      int lx = 0;
+      for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
+      const int sself = T.rowoff[hr] + eh;
+      const Vec4<R> xi = sx[sself];
+      const int ti = real_as_idx(xi.w) & 15, tgi = tag[p];
+      const int si = state[tgi], ri = res_id[tgi], mi = mol_id[tgi];
+      bool any = false;
+      for (int k = 0; k < rs.n; ++k) {
+        const ReactionDev& R_ = rs.r[k];
+        if (R_.active) any |= (ti == R_.type_1 && si >= R_.min1 && si < R_.max1) || (ti == R_.type_2 && si >= R_.min2 && si < R_.max2);
+      }
+      if (!any) continue;
+      const Vec4<R> xgi = x4[p];
+#pragma unroll 1
+      for (int dzy = 0; dzy < 9; ++dzy) {
+        const int dz = dzy / 3, dy = dzy - 3 * dz;
+        const int r = (lz + dz) * SY + (ly + dy);
+        const int a = T.rowoff[r] + T.celloff[r][lx];
+        int b = T.rowoff[r] + T.celloff[r][lx + 3];
+        b = b < total ? b : total;
+        for (int sl = a; sl < b; ++sl) {
+          const Vec4<R> xj = sx[sl];
+          const R dx = xi.x - xj.x, dy_ = xi.y - xj.y, dz_ = xi.z - xj.z;
+          if (dx * dx + dy_ * dy_ + dz_ * dz_ > maxcut2 || sl == sself) continue;
+          const int jw = real_as_idx(xj.w), j = jw >> 5, tj = jw & 15;
+          const int tgj = tag[j];
+          if (!(tgi < tgj)) continue;          // every pair once, from its lower tag (on the rank that owns it)
+          const int sj = state[tgj], rj = res_id[tgj], mj = mol_id[tgj];
+          const D3 d = minimgD(box, posD<R>(xgi) - posD<R>(x4[j]));
+          const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(d.x, d.x), __dmul_rn(d.y, d.y)), __dmul_rn(d.z, d.z));
+          for (int k = 0; k < rs.n; ++k) {
+            const ReactionDev& R_ = rs.r[k];
+            if (!R_.active) continue;
+            const bool fwd = ti == R_.type_1 && si >= R_.min1 && si < R_.max1 && tj == R_.type_2 && sj >= R_.min2 && sj < R_.max2;
+            const bool rev = tj == R_.type_1 && sj >= R_.min1 && sj < R_.max1 && ti == R_.type_2 && si >= R_.min2 && si < R_.max2;
+            if (!(fwd || rev)) continue;
+            if (!R_.intraresidual && ri == rj) continue;
+            if (!R_.intramolecular && mi == mj) continue;
+            if (!(d2 >= R_.mincut2 && d2 < R_.cut2)) continue;
+            uint32_t rr[4];
+            chem_philox::reaction_draw(rs.seed, rs.step, (uint32_t)tgi, (uint32_t)tgj, (uint32_t)k, rr);
+            if (R_.prob < 1.0 && !(chem_philox::u01(rr[0]) < R_.prob)) continue;
+            const int idx = atomicAdd(&s_cnt, 1);
+            if (idx < region_cap) out[idx] = fwd ? Candidate{tgi, tgj, k, rr[1], d2} : Candidate{tgj, tgi, k, rr[1], d2};   // tgi < tgj: forward role assignment wins
+            else ctl->cand_overflow = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_count[tile] = s_cnt < region_cap ? s_cnt : region_cap;
+  }
+}
+
+// exclusive scan of the per-tile candidate counts (single block) -> tile_off, total -> ctl->cand_count
+__global__ __launch_bounds__(1024) void k_cand_offsets(int ntiles, const int* __restrict__ tile_count, int* __restrict__ tile_off, DevCtl* ctl) {
+  __shared__ int ws[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int w = threadIdx.x >> 6, lane = lane_id();
+  for (int base = 0; base < ntiles; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < ntiles ? tile_count[i] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) ws[w] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) off += ws[k]; tot += ws[k]; }
+    if (i < ntiles) tile_off[i] = carry_s + off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) ctl->cand_count = carry_s;
+}
+
+__global__ __launch_bounds__(256) void k_cand_gather(int ntiles, const Candidate* __restrict__ region, int region_cap, const int* __restrict__ tile_count,
+                                                     const int* __restrict__ tile_off, Candidate* __restrict__ cand, int cand_cap, DevCtl* ctl) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int c = tile_count[tile], o = tile_off[tile];
+    const Candidate* src = region + (size_t)tile * region_cap;
+    for (int k = threadIdx.x; k < c; k += blockDim.x) { if (o + k < cand_cap) cand[o + k] = src[k]; else ctl->cand_overflow = 1; }
+  }
+}
+
 // ---- resolve: UniqueA, UniqueB, one-event-per-particle (parallel greedy) -------------
 __device__ __forceinline__ unsigned long long cand_key1(const Candidate& c, int nearest) {
   return nearest ? (unsigned long long)__double_as_longlong(c.d2) : (unsigned long long)c.h;

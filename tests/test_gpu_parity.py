@@ -482,3 +482,132 @@ def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mo
     assert out["gpu"]["bonds"] == out["oracle"]["bonds"]
     assert np.array_equal(out["gpu"]["st"], out["oracle"]["st"]) and np.array_equal(out["gpu"]["ty"], out["oracle"]["ty"])
     assert rel_err(out["gpu"]["x"], out["oracle"]["x"]) < 1e-7
+
+
+# ---- edge cases and size-independent properties ---------------------------------------------------
+def test_positions_outside_the_box_and_on_its_faces_are_folded(make_gpu, make_oracle):
+    """Inputs the readers can produce: coordinates at exactly 0 and L, negative, several box lengths away."""
+    spec = W.lj_melt(n=2048, seed=9, jitter=0.05)
+    L = spec["box"][0]
+    pos = spec["pos"].copy()
+    # rigid shifts (no overlaps are created) that put particle 3 exactly on x = 0, particle 4 on y = L and
+    # particle 5 on z = -0.0; everything pushed past a face by that must be folded back by the engine
+    pos[:, 0] -= pos[3, 0]; pos[:, 1] += L - pos[4, 1]; pos[:, 2] -= pos[5, 2]
+    pos[3, 0] = 0.0; pos[4, 1] = L; pos[5, 2] = -0.0
+    pos[0] += [L, 0, 0]; pos[1] -= [0, 2 * L, 0]; pos[2] += [3 * L, -L, 5 * L]
+    spec["pos"] = pos
+    g, o, _ = both(make_gpu, make_oracle, spec, 64, thermostat=False)
+    g.run(0); o.run(0)
+    assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-10
+    g.run(20); o.run(20)
+    assert np.array_equal(g.get_state("IMAGE"), o.get_state("IMAGE"))
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_run_is_additive_and_repeatable(make_gpu, prec):
+    """Without a thermostat run(a); run(b) == run(a+b) bit for bit: the force evaluation that opens every
+    run() must not change the state.  (With Langevin the opening evaluation draws fresh noise, as
+    ESPResSo++'s run() does -- SURVEY 3.3 -- so only repeatability is required there.)  Reactions,
+    rebuilds, new bonds and exclusions are active in both halves of the test."""
+    spec = W.reactive_melt(n=8788, seed=31, interval=15)
+    a, b = make_gpu(prec), make_gpu(prec)
+    for e in (a, b):
+        W.apply(spec, e, thermostat=False)
+    a.run(45)
+    b.run(7); b.run(0); b.run(20); b.run(18)        # never split right after a reaction step: a new run()
+    assert len(a.get_events()) > 500                 # re-evaluates forces with the new bonds, a running one does not
+    assert sorted_events(a.get_events()) == sorted_events(b.get_events())
+    for what in ("POS", "VEL", "STATE", "TYPE", "RESID", "MOLID"):
+        assert np.array_equal(a.get_state(what), b.get_state(what)), what
+    c, d = make_gpu(prec), make_gpu(prec)
+    for e in (c, d):
+        W.apply(spec, e)                                   # Langevin on
+        e.run(20); e.run(25)
+    assert len(c.get_events()) > 500
+    assert sorted_events(c.get_events()) == sorted_events(d.get_events())
+    for what in ("POS", "VEL", "STATE", "TYPE"):
+        assert np.array_equal(c.get_state(what), d.get_state(what)), what
+
+
+def test_reactions_without_candidates_and_two_particle_system(make_gpu, make_oracle):
+    spec = W.reactive_melt(n=4000, seed=14, interval=5)
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 0.0                                     # probability 0: scans run, nothing may happen
+    g, o, h = both(make_gpu, make_oracle, spec, 64)
+    g.run(20); o.run(20)
+    assert len(g.get_events()) == 0 and len(o.get_events()) == 0
+    assert g.get_list(h["reaction_bonds"]).shape[0] == 0
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+    # two particles, one bond, no non-bonded partner inside the cut-off: the smallest valid system
+    two = dict(n=2, box=[12.0, 12.0, 12.0], rc=2.5, skin=0.3, dt=0.002, ids=np.array([5, 9]), types=np.zeros(2, np.int32),
+               pos=np.array([[1.0, 1.0, 1.0], [11.6, 1.0, 1.0]]), vel=np.zeros((2, 3)), mass=np.array([1.0, 2.0]),
+               lj=[(0, 0, 1.0, 1.0, 2.5)], kT=1.0, gamma=0.0, seed=1,
+               lists=[dict(arity=2, kind="HARMONIC", params=[30.0, 0.97], ids=np.array([[5, 9]]))], exclusions=np.array([[5, 9]]))
+    g2, o2, _ = both(make_gpu, make_oracle, two, 64)
+    g2.run(50); o2.run(50)
+    assert rel_err(g2.get_state("POS_UNFOLDED"), o2.get_state("POS_UNFOLDED")) < 1e-10
+    assert abs(np.asarray(g2.observe()["momentum"])).max() < 1e-12
+
+
+def test_neighbour_capacity_too_small_is_reported(make_gpu):
+    from chemlab_amd.engine import ChemError
+    spec = W.lj_melt(n=4000, seed=3)
+    g = make_gpu(32)
+    W.apply(spec, g, thermostat=False)
+    g.set_nlist_capacity(16)            # ~70 neighbours needed
+    with pytest.raises(ChemError) as ei:
+        g.run(1)
+    assert "capacity" in str(ei.value)
+
+
+def test_full_size_properties_one_million_particles(make_gpu):
+    """BASELINE size (the bench workload): properties that need no oracle run.
+    * one event per particle and reaction step, bonds unique, exclusions = bonds (both ends known to the log);
+    * NVE momentum conserved to fp32 summation noise;
+    * a second engine reproduces events and positions bit for bit."""
+    spec = W.reactive_melt(n=1000000, rho=0.8, seed=2, interval=40)
+    a, b = make_gpu(32), make_gpu(32)
+    for e in (a, b):
+        W.apply(spec, e, thermostat=False)
+    p0 = np.asarray(a.observe()["momentum"])
+    a.run(80); b.run(80)
+    ev = a.get_events()
+    assert len(ev) > 100000
+    for st in np.unique(ev["step"]):
+        blk = ev[ev["step"] == st]
+        ids = np.concatenate([blk["id_a"], blk["id_b"]])
+        assert len(np.unique(ids)) == len(ids)
+    assert np.array_equal(ev, b.get_events())
+    assert np.array_equal(a.get_state("POS"), b.get_state("POS"))
+    ex = a.get_exclusions()
+    key = np.sort(ex, 1)
+    assert len(np.unique(key[:, 0] * (1 << 32) + key[:, 1])) == len(ex)
+    in_log = np.zeros(spec["n"] + 2, bool)
+    in_log[ev["id_a"]] = True; in_log[ev["id_b"]] = True
+    assert in_log[ex].all()
+    p1 = np.asarray(a.observe()["momentum"])
+    assert np.abs(p1 - p0).max() < 2e-2 * np.sqrt(spec["n"])     # |p| per particle ~1: relative 2e-5 of the random-sum scale
+    assert a.timers()["rebuilds"] >= 5
+
+
+@pytest.mark.parametrize("transport", [None, "dd_self"])
+def test_one_run_across_reaction_steps_matches_oracle(make_gpu, make_oracle, transport):
+    """Regression: the reaction sits between the force evaluation of step s and the first kick of step s+1.
+    A list rebuild at the reaction step used to re-sort the particles (and, decomposed, migrate them) away
+    from their forces; every parity test that steps in chunks of `interval` missed it because a new run()
+    re-evaluates the forces first.  One run() over three reaction steps, single domain and decomposed."""
+    spec = W.reactive_melt(n=8788, seed=31, interval=15)
+    spec["rebuild_criterion"] = 0
+    g, o = make_gpu(64), make_oracle()
+    if transport:
+        g.set_option(transport, 1)
+    hg = W.apply(spec, g, thermostat=False); ho = W.apply(spec, o, thermostat=False)
+    g.run(50); o.run(50)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 1500 and [e[:4] for e in eg] == [e[:4] for e in eo]
+    assert np.array_equal(g.get_list(hg["reaction_bonds"]), o.get_list(ho["reaction_bonds"]))
+    assert len(g.get_list(hg["reaction_bonds"])) > 50
+    assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < 1e-8
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
