@@ -611,3 +611,29 @@ def test_one_run_across_reaction_steps_matches_oracle(make_gpu, make_oracle, tra
     assert len(g.get_list(hg["reaction_bonds"])) > 50
     assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < 1e-8
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+
+
+@pytest.mark.parametrize("transport", [None, "dd_self"])
+def test_irregular_run_lengths_with_thermostat_and_late_enable(make_gpu, make_oracle, transport):
+    """Run lengths that are no multiple of the reaction interval, Langevin on, reactions switched on after the
+    first run and off again before the last (start_simulation.py's start_ar/stop_ar) -- the caller decides
+    where run() boundaries fall, the trajectory must not care beyond what the reference itself does."""
+    spec = W.reactive_melt(n=8788, seed=17, interval=12)
+    spec["rebuild_criterion"] = 0
+    g, o = make_gpu(64), make_oracle()
+    if transport:
+        g.set_option(transport, 1)
+    hg = W.apply(spec, g); ho = W.apply(spec, o)
+    for e in (g, o):
+        e.reactions_enable(False)
+        e.run(7)
+        e.reactions_enable(True)
+        e.run(23); e.run(40)
+        e.reactions_enable(False)
+        e.run(9)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 1500 and [e[:4] for e in eg] == [e[:4] for e in eo]
+    assert sorted({e[0] for e in eo}) == [12, 24, 36, 48, 60]
+    assert np.array_equal(g.get_list(hg["reaction_bonds"]), o.get_list(ho["reaction_bonds"]))
+    assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
