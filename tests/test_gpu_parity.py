@@ -426,13 +426,15 @@ def test_dd_multi_rank_in_process_lj(make_gpu, make_oracle, P, n):
         assert out[r]["reb"] >= 4
 
 
-def test_dd_multi_rank_in_process_reactive(make_gpu, make_oracle):
+@pytest.mark.parametrize("chunks", [(25, 25, 25), (75,), (10, 41, 24)])
+def test_dd_multi_rank_in_process_reactive(make_gpu, make_oracle, chunks):
+    # chunks: run() boundaries on, beyond and between the reaction steps (25, 50, 75)
     P = 2
     spec = W.reactive_melt(n=8788, seed=12, interval=25)
     o = make_oracle()
     ho = W.apply(spec, o)
-    for _ in range(3):
-        o.run(25)
+    for k in chunks:
+        o.run(k)
     engs = [make_gpu(64) for _ in range(P)]
     _HUB[0] += 1
     hub = _HUB[0]
@@ -441,8 +443,8 @@ def test_dd_multi_rank_in_process_reactive(make_gpu, make_oracle):
         g = engs[r]
         g.comm_init_local(P, r, hub)
         h = W.apply(spec, g)
-        for _ in range(3):
-            g.run(25)
+        for k in chunks:
+            g.run(k)
         return dict(ev=sorted_events(g.get_events()), bonds=g.get_list(h["reaction_bonds"]), st=g.get_state("STATE"),
                     ty=g.get_state("TYPE"), x=g.get_state("POS_UNFOLDED"), el=g.observe()["epot_list"])
     out = _run_ranks(P, rank)
