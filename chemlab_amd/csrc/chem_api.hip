@@ -674,7 +674,23 @@ template <typename R> struct CtxT : Ctx {
       if (dd_on) agree_flags(h);
       if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
       if (h.barrier_timeout) throw ChemError(CHEM_ESTATE, "fused rebuild: grid barrier timed out (device shared with another job?); set option fused_rebuild=0");
-      if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil holds " + std::to_string(h.stage_overflow) + " particles, LDS tile capacity " + std::to_string(use_tiles ? tile_cap : 1536) + " (density fluctuation beyond the 12 % margin)");
+      if (h.stage_overflow) {
+        // denser than the mean-occupancy estimate (clusters, chains): grow the staged-tile capacity while it
+        // fits the LDS, then build again; beyond that the system is too crowded for tiles
+        const int want = (h.stage_overflow + h.stage_overflow / 8 + 255) / 256 * 256;
+        const int old_cap = tile_cap;
+        if (use_tiles && want > tile_cap) {
+          tile_cap = want;
+          if (tile_lds_bytes() <= (size_t)150 * 1024) {
+            set_tile_lds_attr(); setup_fused();
+            set_ctl_field(&DevCtl::stage_overflow, 0);
+            if (g_trace) fprintf(stderr, "[chem trace] staged-tile capacity %d -> %d slots\n", old_cap, tile_cap);
+            continue;
+          }
+          tile_cap = old_cap;
+        }
+        throw ChemError(CHEM_ENOSPC, "cell stencil holds " + std::to_string(h.stage_overflow) + " particles, LDS tile capacity " + std::to_string(use_tiles ? tile_cap : 1536) + " (local density too high for the LDS-staged tiles; set option tiles=0)");
+      }
       if (!h.nl_overflow) { resort = false; tm.rebuild_wall_s += now_s() - t0; return; }
       int newS = ((int)(h.nl_overflow * 1.25) + 31) / 16 * 16;
       if (nl_capacity_user > 0) throw ChemError(CHEM_ENOSPC, "neighbour capacity " + std::to_string(S) + " too small, need " + std::to_string(h.nl_overflow));

@@ -639,3 +639,25 @@ def test_irregular_run_lengths_with_thermostat_and_late_enable(make_gpu, make_or
     assert np.array_equal(g.get_list(hg["reaction_bonds"]), o.get_list(ho["reaction_bonds"]))
     assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_dense_slab_grows_the_tile_capacity(make_gpu, make_oracle, prec):
+    """Half the box empty, the other half at twice the mean density: the staged-tile capacity derived from the
+    mean occupancy is too small; the first build must notice, grow it and build again (not fail, not truncate)."""
+    k = 16
+    a = 0.96                                                 # simple cubic, nearest neighbours at 0.96 sigma
+    g1 = np.arange(k)
+    pos = np.stack(np.meshgrid(np.arange(2 * k), g1, g1, indexing="ij"), -1).reshape(-1, 3).astype(np.float64)
+    pos = pos[pos[:, 0] < k] * a + 0.3                       # k^3 particles in the x < L/2 half
+    n = len(pos)
+    rng = np.random.default_rng(5)
+    pos += rng.uniform(-0.02, 0.02, pos.shape)
+    L = [2 * k * a, k * a, k * a]
+    spec = dict(n=n, box=L, rc=2.5, skin=0.3, dt=0.001, ids=np.arange(1, n + 1), types=np.zeros(n, np.int32), pos=pos,
+                vel=np.zeros((n, 3)), mass=np.ones(n), lj=[(0, 0, 1.0, 1.0, 2.5)], kT=1.0, gamma=0.0, seed=1)
+    g, o, _ = both(make_gpu, make_oracle, spec, prec, thermostat=False)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[prec]
+    if prec == 64:
+        assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
