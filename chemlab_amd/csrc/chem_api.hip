@@ -104,6 +104,9 @@ struct Ctx {
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
   int opt_fused = 1;        // rebuild chain as one persistent launch with grid barriers (single domain, tiles)
   int pair_guard = 0;       // 256 while the force kernels are launched speculatively (decomposed path)
+  int pair_subset = 0;      // 0 all tiles, 1 interior tiles of the slab, 2 its two boundary tile layers
+  int opt_overlap = -1;     // decomposed path: interior forces while the halo exchange is in flight (-1: automatic, by slab size)
+  hipStream_t cstream = nullptr; hipEvent_t ev_fold = nullptr, ev_halo = nullptr;
   int opt_criterion = 0;     // 1: rebuild when max |x - x(last build)| > skin/2 ; 0: reference's accumulated per-step maxima
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
@@ -203,6 +206,7 @@ template <typename R> struct CtxT : Ctx {
     for (auto e : ev) (void)hipEventDestroy(e);
     if (pin_ev) (void)hipHostFree(pin_ev);
     if (hflag) (void)hipHostFree(hflag);
+    if (cstream) { (void)hipStreamSynchronize(cstream); (void)hipStreamDestroy(cstream); (void)hipEventDestroy(ev_fold); (void)hipEventDestroy(ev_halo); }
     if (stream) (void)hipStreamDestroy(stream);
   }
   void sync() override { HIPCHK(hipStreamSynchronize(stream)); }
@@ -721,8 +725,15 @@ template <typename R> struct CtxT : Ctx {
   template <bool ENERGY> int launch_pair(V4* fdst, int tpp) {
     const double hs = 0.5 * skin;
     if (use_tiles) {
-#define LT(T, M, B) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M>), dim3(ntiles), dim3(B), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, fdst, tdesc.p, \
-                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, opt_ablate | pair_guard, dbg_on ? dbgbuf.p : (long long*)nullptr)
+      // which tiles: all (default), or the interior / boundary subset of a slab (see TileSub)
+      const int ntxy = ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY);
+      TileSub ts{0, ntiles, 0};
+      int nsub = ntiles;
+      if (pair_subset == 1) { ts = TileSub{ntxy, ntiles - 2 * ntxy, 0}; nsub = ntiles - 2 * ntxy; }
+      else if (pair_subset == 2) { ts = TileSub{0, ntxy, ntiles - ntxy}; nsub = 2 * ntxy; }
+      if (nsub <= 0) return 0;
+#define LT(T, M, B) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M>), dim3(nsub), dim3(B), tile_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
+                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, opt_ablate | pair_guard, dbg_on ? dbgbuf.p : (long long*)nullptr, ts)
 #define LTB(T, M) do { if (pair_bs == 256) LT(T, M, 256); else if (pair_bs == 512) LT(T, M, 512); else LT(T, M, 1024); } while (0)
 #define LTT(M) do { switch (tpp) { case 1: LTB(1, M); break; case 2: LTB(2, M); break; case 8: LTB(8, M); break; default: LTB(4, M); break; } } while (0)
       const int mode = ENERGY ? 0 : (uniform_lj ? 2 : (lj_only ? 1 : 0));
@@ -743,13 +754,16 @@ template <typename R> struct CtxT : Ctx {
     return nb;
   }
 
-  void compute_forces(bool speculative = false) {
+  void compute_forces(bool speculative = false, int subset = 0) {
     pair_guard = speculative ? 256 : 0;
+    pair_subset = subset;
     const int tpp = pick_tpp();
     const bool timed = opt_time_pair && !speculative && (pair_launch_no++ % opt_time_pair) == 0 && ev_used + 2 <= ev.size();
     if (timed) HIPCHK(hipEventRecord(ev[ev_used], stream));
     launch_pair<false>(f4.p, tpp);
     if (timed) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; }
+    pair_subset = 0;
+    if (subset == 1) { pair_guard = 0; return; }   // interior tiles only: bonded terms follow with the boundary launch
     if (nbent > 0 && (use_fused || dd_on)) {
       // work-list kernel: owners only, partner indices resolved at the last rebuild
       if (bwork_dirty) {   // bonded lists changed without a rebuild since
@@ -810,15 +824,39 @@ template <typename R> struct CtxT : Ctx {
     // word (no memcpy, no stream synchronisation call)
     hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), 256), 0.5 * skin, opt_criterion, 1,
                        (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+    // Overlap: the halo exchange runs on the communication stream while the tiles that need no ghost
+    // (every tile layer but the lowest and the highest of the slab) already compute their forces.
+    // Those launches cannot know the decision yet; if it is "rebuild", everything is recomputed below.
+    const int ntxy = ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY);
+    // Measured with one rank (1M particles, RCCL to self): the cross-stream hand-over costs ~15 us and the
+    // boundary launch cannot fill the chip, so the overlap only pays once the interior force kernel is much
+    // longer than that -- automatic for slabs of >= 8192 tiles (~4M particles per GPU), option overlap_halo.
+    const bool want_overlap = opt_overlap > 0 || (opt_overlap < 0 && ntiles >= 8192);
+    const bool overlap = want_overlap && use_tiles && ntiles > 2 * ntxy && !getenv("CHEM_DD_NOPOLL");
+    hipStream_t xs = stream;
+    if (overlap) {
+      if (!cstream) {
+        HIPCHK(hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev_fold, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
+      }
+      HIPCHK(hipEventRecord(ev_fold, stream));
+      HIPCHK(hipStreamWaitEvent(cstream, ev_fold, 0));
+      xs = cstream;
+    }
     tr->exchange_with_scalar(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
-                             x4.p + G - nglo, nglo * sizeof(V4), lower, upper, &ctl.p->step_m2, dd_vals.p, stream);
+                             x4.p + G - nglo, nglo * sizeof(V4), lower, upper, &ctl.p->step_m2, dd_vals.p, xs);
+    if (overlap) {
+      HIPCHK(hipEventRecord(ev_halo, cstream));
+      compute_forces(false, 1);                    // interior tiles, main stream, concurrent with the exchange
+      HIPCHK(hipStreamWaitEvent(stream, ev_halo, 0));
+    }
     const int ticket = ++hticket;
     hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, 0, 0.5 * skin, opt_criterion, 2,
                        dd_vals.p, P, (volatile int*)hflag_dev, ticket);
     // The force kernels are enqueued BEFORE the host looks at the decision: they leave at once when a
     // rebuild is pending (then the host rebuilds and launches them again), otherwise the device never
     // waits for the host's poll + launch latency.
-    compute_forces(true);
+    compute_forces(true, overlap ? 2 : 0);
     if (getenv("CHEM_DD_NOPOLL")) { DevCtl hc = read_ctl(); if (hc.need_rebuild) { rebuild_dd(); compute_forces(); } return; }
     volatile int* hf = hflag;
     poll_ticket(hflag + 1, ticket, "rebuild decision");
@@ -1622,6 +1660,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else if (k == "fused_rebuild") { CTX.opt_fused = value != 0; CTX.geom_dirty = true; }
+  else if (k == "overlap_halo") CTX.opt_overlap = value < 0 ? -1 : (value != 0 ? 1 : 0);
   else if (k == "pair_block") { const int v = (int)value; REQUIRE(v == 256 || v == 512 || v == 1024, CHEM_EINVAL, "pair_block must be 256, 512 or 1024"); CTX.set_pair_bs(v); }
   else if (k == "ablate") CTX.opt_ablate = (int)value;
   else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; }

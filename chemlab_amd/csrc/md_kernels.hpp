@@ -1212,13 +1212,18 @@ struct UniLJ { float rc2, lj1, lj2, pad; double drc2, dlj1, dlj2; };   // all li
 // One workgroup per tile; TPP lanes per home particle (lane `sub` takes chunks sub, sub+TPP, ...).
 // MODE 0: general (type-pair table in LDS, tables allowed)  1: LJ/off pairs only, branch-free
 //      2: uniform LJ -- every listed pair has the same parameters (kernel arguments / SGPRs)
+// Tiles of one launch: [base1, base1+n1) followed by [base2, ...).  The decomposed path launches the
+// tiles whose stencil stays inside the own layers ("interior": they need no ghost) while the halo
+// exchange is still in flight on the communication stream, and the two boundary tile layers after it.
+struct TileSub { int base1, n1, base2; };
+
 template <typename R, int TPP, bool ENERGY, int BS, int MODE>
 __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
                                                    const TileLDS<R>* __restrict__ desc, const unsigned short* __restrict__ nl16,
                                                    const int* __restrict__ nnh, int S16,
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
                                                    int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
-                                                   double half_skin, DevCtl* ctl, int ablate, long long* __restrict__ dbg) {
+                                                   double half_skin, DevCtl* ctl, int ablate, long long* __restrict__ dbg, TileSub sub_) {
   constexpr bool LJONLY = MODE >= 1;
   constexpr int NCH = TPP == 1 ? 3 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
@@ -1233,7 +1238,8 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
   if (blockIdx.x == 0 && threadIdx.x == 0 && ctl->acc_maxdist > half_skin) ctl->skin_violation = 1;
   const R u_rc2 = sizeof(R) == 4 ? (R)uni.rc2 : (R)uni.drc2, u_lj1 = sizeof(R) == 4 ? (R)uni.lj1 : (R)uni.dlj1,
           u_lj2 = sizeof(R) == 4 ? (R)uni.lj2 : (R)uni.dlj2;
-  const int tile = xcd_remap(blockIdx.x, ntiles);
+  const int vtile = xcd_remap(blockIdx.x, ntiles);   // ntiles = tiles of THIS launch (all of them, or one of the two subsets below)
+  const int tile = vtile < sub_.n1 ? sub_.base1 + vtile : sub_.base2 + (vtile - sub_.n1);
   tile_load_desc<R>(T, desc, tile);
   __syncthreads();
   if (ablate == 3) return;   // diagnostic: descriptor load only

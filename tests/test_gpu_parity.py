@@ -594,7 +594,7 @@ def test_full_size_properties_one_million_particles(make_gpu):
     assert a.timers()["rebuilds"] >= 5
 
 
-@pytest.mark.parametrize("transport", [None, "dd_self"])
+@pytest.mark.parametrize("transport", [None, "dd_self", "dd_self_rccl+overlap"])
 def test_one_run_across_reaction_steps_matches_oracle(make_gpu, make_oracle, transport):
     """Regression: the reaction sits between the force evaluation of step s and the first kick of step s+1.
     A list rebuild at the reaction step used to re-sort the particles (and, decomposed, migrate them) away
@@ -604,7 +604,9 @@ def test_one_run_across_reaction_steps_matches_oracle(make_gpu, make_oracle, tra
     spec["rebuild_criterion"] = 0
     g, o = make_gpu(64), make_oracle()
     if transport:
-        g.set_option(transport, 1)
+        g.set_option(transport.split("+")[0], 1)
+        if transport.endswith("+overlap"):                 # interior tiles computed while the halo is in flight
+            g.set_option("overlap_halo", 1)
     hg = W.apply(spec, g, thermostat=False); ho = W.apply(spec, o, thermostat=False)
     g.run(50); o.run(50)
     eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
