@@ -922,6 +922,40 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
   }
 }
 
+// List build, fp32: the stencil staged as PAIRS of slots in SoA order -- 32 bytes per pair:
+// (x0 x1 y0 y1 | z0 z1 w0 w1) -- so that the distance test of two candidates is three v_pk_add_f32,
+// one v_pk_mul_f32 and two v_pk_fma_f32 on whole ds_read_b128 results (packed fp32 runs at twice the
+// scalar rate on CDNA3/4; with the per-slot float4 layout the compiler needs v_mov shuffles to pair
+// the operands up and gains nothing).  .w = (global index << 5 | type) as in tile_fill's wmode 1.
+template <int BS>
+__device__ __forceinline__ int pair_off(int s, int c) { return (s >> 1) * 8 + c * 2 + (s & 1); }
+template <int BS>
+__device__ __forceinline__ void tile_fill_pairs(const TileLDS<float>& T, float* const sf, const int CAP, const float4* __restrict__ x4) {
+  constexpr int NW = BS / 64;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (threadIdx.x < 2) {   // far-away dummy in the two slots behind the image (reads run past the last run)
+    const int s = T.geom[3] + (int)threadIdx.x;
+    sf[pair_off<BS>(s, 0)] = 1e18f; sf[pair_off<BS>(s, 1)] = 1e18f; sf[pair_off<BS>(s, 2)] = 1e18f; sf[pair_off<BS>(s, 3)] = 0.f;
+  }
+  for (int r = w; r < NROW; r += NW) {
+    const int len = T.celloff[r][SX], o0 = T.rowoff[r];
+    for (int e = l; e < len; e += 64) {
+      int k = 0;
+#pragma unroll
+      for (int q = 1; q < SX; ++q) k += (e >= T.celloff[r][q]) ? 1 : 0;
+      const int g = T.cellg[r][k] + (e - T.celloff[r][k]);
+      const int dst = o0 + e;
+      if (dst < CAP) {
+        const float4 p = x4[g];
+        sf[pair_off<BS>(dst, 0)] = p.x + T.cellshx[r][k];
+        sf[pair_off<BS>(dst, 1)] = p.y + T.rowshy[r];
+        sf[pair_off<BS>(dst, 2)] = p.z + T.rowshz[r];
+        sf[pair_off<BS>(dst, 3)] = __int_as_float((g << 5) | (int)p.w);
+      }
+    }
+  }
+}
+
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 nt_load_u4(const uint4* p) {
   const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
@@ -974,7 +1008,11 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
       int lx = 0;
       for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
       const int sself = T.rowoff[hr] + eh;
-      const Vec4<R> xi = sx[sself];
+      Vec4<R> xi;
+      if constexpr (sizeof(R) == 4) {   // paired SoA image (tile_fill_pairs)
+        const float* sf = reinterpret_cast<const float*>(sx);
+        xi = mk4<R>(sf[pair_off<BS>(sself, 0)], sf[pair_off<BS>(sself, 1)], sf[pair_off<BS>(sself, 2)], sf[pair_off<BS>(sself, 3)]);
+      } else xi = sx[sself];
       const unsigned int arow = act.row[real_as_idx(xi.w) & 15];
       int e0 = 0, e1 = 0;
       if (has_excl) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
@@ -1052,35 +1090,41 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
         int b = T.rowoff[r] + T.celloff[r][lx + 3];
         b = b < total ? b : total;
         if constexpr (sizeof(R) == 4) {
-          // fp32 fast path: 32-candidate segments, one 32-bit shift-register mask per lane.  Each test
-          // is ds_read_b128 + 3 sub + mul + 2 fma + v_cmp + v_addc (carry shifts the result in);
-          // reads run up to 3 slots past the run (the LDS image has 4 slack slots), the surplus
-          // bits are masked off afterwards instead of selecting a dummy address per candidate.
+          // fp32 fast path: 32-candidate segments (16 slot pairs), one 32-bit shift-register mask per
+          // lane.  Two candidates per packed instruction: 3 v_pk_add + v_pk_mul + 2 v_pk_fma, then per
+          // candidate v_cmp + v_addc (the carry shifts the result in) and v_bfe + v_lshl_or for the
+          // type-pair filter.  Segments start on an even slot; the slot in front of an odd run start and
+          // the (up to 3) slots behind the run are tested too and masked off afterwards.
           typedef float f32x4 __attribute__((ext_vector_type(4)));
-          for (int s0 = a; s0 < b; s0 += 32) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef __attribute__((address_space(3))) const volatile f32x4 lds_f32x4;   // volatile: keeps the 16-byte reads
+          const f32x2 xix = {xi.x, xi.x}, xiy = {xi.y, xi.y}, xiz = {xi.z, xi.z};
+          for (int s0 = a & ~1; s0 < b; s0 += 32) {
             const int len = (b - s0) < 32 ? (b - s0) : 32;
             const int ng = (len + 3) >> 2;
             unsigned int m = 0, ma = 0;
-            typedef __attribute__((address_space(3))) const volatile f32x4 lds_f32x4;
-            lds_f32x4* base = (lds_f32x4*)(sx) + s0;     // volatile: keeps the 16-byte read (b128 costs half the LDS cycles of b96)
+            lds_f32x4* base = (lds_f32x4*)(sx) + s0;      // pair p = slot/2 lives at float4 index 2p, 2p+1 = slots s0, s0+1
             for (int g = 0; g < ng; ++g) {
-              f32x4 xj[4];
+              f32x4 A[2], B[2];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) xj[u] = base[4 * g + u];
+              for (int u = 0; u < 2; ++u) { A[u] = base[4 * g + 2 * u]; B[u] = base[4 * g + 2 * u + 1]; }
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const float dx = xi.x - xj[u].x, dy_ = xi.y - xj[u].y, dz_ = xi.z - xj[u].z;
-                const float r2 = dx * dx + dy_ * dy_ + dz_ * dz_;
-                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r2), "v"(rl2) : "vcc");
-                ma = (ma << 1) | __builtin_amdgcn_ubfe(arow, __float_as_uint(xj[u].w), 1u);   // type pair carries a potential
+              for (int u = 0; u < 2; ++u) {
+                const f32x2 dx = xix - A[u].xy, dy_ = xiy - A[u].zw, dz_ = xiz - B[u].xy;
+                const f32x2 r2 = dx * dx + dy_ * dy_ + dz_ * dz_;
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r2.x), "v"(rl2) : "vcc");
+                ma = (ma << 1) | __builtin_amdgcn_ubfe(arow, __float_as_uint(B[u].z), 1u);   // type pair carries a potential
+                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r2.y), "v"(rl2) : "vcc");
+                ma = (ma << 1) | __builtin_amdgcn_ubfe(arow, __float_as_uint(B[u].w), 1u);
               }
             }
             m <<= 32 - 4 * ng;                                     // candidate u -> bit 31-u
             m &= ~(len < 32 ? (0xffffffffu >> len) : 0u);
+            if (s0 < a) m &= 0x7fffffffu;                          // the slot in front of an odd run start
             if (plain) {
-              // no exclusions and no int32 row for this particle: the type filter was folded into the
-              // test loop (ma) and the self pair is cleared from the mask, so a hit needs nothing from
-              // memory and the peel loop has no LDS latency in it
+              // no exclusions (or located as slots) and no int32 row for this particle: the type filter was
+              // folded into the test loop (ma) and the self pair is cleared from the mask, so a hit needs
+              // nothing from memory and the peel loop has no LDS latency in it
               m &= ma << (32 - 4 * ng);
               const unsigned int ks = (unsigned int)(sself - s0);
               if (ks < 32u) m &= ~(0x80000000u >> ks);
@@ -1097,11 +1141,12 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
                 push((unsigned int)(s0 + k));
               }
             } else {
+              const float* sf = reinterpret_cast<const float*>(sx);
               while (m) {
                 const int k = __clz((int)m);
                 m &= ~(0x80000000u >> k);
                 const int sl = s0 + k;
-                hit(sl, real_as_idx(sx[sl].w));
+                hit(sl, __float_as_int(sf[pair_off<BS>(sl, 3)]));
               }
             }
           }
@@ -1160,7 +1205,8 @@ __global__ __launch_bounds__(BS, 6) void k_nlist_tiles(int ntiles, int CAP, cons
     __syncthreads();
     tile_load_desc<R>(T, desc, tile);
     __syncthreads();
-    tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
+    if constexpr (sizeof(R) == 4) tile_fill_pairs<BS>(T, reinterpret_cast<float*>(sx), CAP, x4);
+    else tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
     __syncthreads();
     dev_nlist_tile<R, BS>(T, sx, tag, rl2, excl_start, excl_list, has_excl, act, nl16, S16, nnh, nlist, S, nn, ctl);
   }
@@ -1735,7 +1781,8 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
       tile_load_desc<R>(T, a.desc, tile);
       __syncthreads();
       if (t == 0) { const int hb = a.tloc[tile] + s_off[tile >> a.tseg_shift]; T.geom[5] = hb; a.desc[tile].geom[5] = hb; }
-      tile_fill<R, BS, true>(T, sx, a.CAP, a.x4, 1);
+      if constexpr (sizeof(R) == 4) tile_fill_pairs<BS>(T, reinterpret_cast<float*>(sx), a.CAP, a.x4);
+      else tile_fill<R, BS, true>(T, sx, a.CAP, a.x4, 1);
       __syncthreads();
       dev_nlist_tile<R, BS>(T, sx, a.tag, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
                             a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4);
