@@ -663,3 +663,51 @@ def test_dense_slab_grows_the_tile_capacity(make_gpu, make_oracle, prec):
     assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[prec]
     if prec == 64:
         assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
+
+
+# ---- BASELINE.json configs[1..3] at their full sizes (production precision fp32 vs the fp64 oracle) ------
+def test_baseline_c2_32k_lj_melt(make_gpu, make_oracle):
+    spec = W.lj_melt(n=32000, rho=0.8, seed=21)
+    g, o, _ = both(make_gpu, make_oracle, spec, 32, thermostat=False)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[32]
+    og, oo = g.observe(), o.observe()
+    assert og["epot_lj"] == pytest.approx(oo["epot_lj"], rel=2e-6)
+    assert og["virial_nb"] == pytest.approx(oo["virial_nb"], rel=1e-5)
+    g.run(20); o.run(20)                                      # NVE, a few rebuilds: fp32 trajectory stays on the fp64 one
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-4
+
+
+def test_baseline_c3_128k_tabulated_polymer_melt(make_gpu, make_oracle):
+    spec = W.polymer_melt(n_chains=4000, chain_len=32, seed=3)       # 128 000 beads, table + bonds + angles + nrexcl 3
+    g, o, _ = both(make_gpu, make_oracle, spec, 32, thermostat=False)
+    g.run(0); o.run(0)
+    # tolerance 5e-4 of the largest force here: K = 1.6e5 bonds turn the fp32 ulp of a coordinate (4e-6 at x ~ 33)
+    # into a force error of 2 K ulp ~ 1.2 on forces of ~3e4; the arithmetic itself is fp64 for bonded terms
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 5e-4
+    og, oo = g.observe(), o.observe()
+    for k in range(2):
+        assert og["epot_list"][k] == pytest.approx(oo["epot_list"][k], rel=1e-5)
+    assert og["epot_tab"] == pytest.approx(oo["epot_tab"], rel=1e-4, abs=1e-2)
+    assert og["list_size"] == oo["list_size"] == [4000 * 31, 4000 * 30]
+
+
+def test_baseline_c4_256k_reactive_one_reaction_step(make_gpu, make_oracle):
+    """256k monomers, one reaction step on frozen fp32-representable positions: the candidate scan over the
+    staged tiles, the resolve and the topology update must give the oracle's events, bonds, states and types."""
+    spec = W.reactive_melt(n=256000, rho=0.8, seed=5, interval=1)
+    spec["pos"] = spec["pos"].astype(np.float32).astype(np.float64)
+    spec["box"] = [float(np.float32(spec["box"][0]))] * 3
+    spec["dt"] = 1e-9
+    spec["vel"] = np.zeros_like(spec["vel"])
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e12
+    g, o, h = both(make_gpu, make_oracle, spec, 32, thermostat=False)
+    g.run(2); o.run(2)                                        # second step: bond-forming reactions see the new states
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 50000 and [e[:4] for e in eg] == [e[:4] for e in eo]
+    assert np.allclose([e[4] for e in eg], [e[4] for e in eo], rtol=1e-6)
+    assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+    assert np.array_equal(g.get_state("TYPE"), o.get_state("TYPE"))
+    assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+    assert np.array_equal(g.get_exclusions(), o.get_exclusions())
