@@ -1703,6 +1703,7 @@ int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], 
           "comm_init: this build decomposes along z only, node grid must be (1,1,nranks)");
   REQUIRE(uid, CHEM_EINVAL, "comm_init: unique id");
   REQUIRE(c.particles_dirty, CHEM_ESTATE, "comm_init must precede the first run (particles are already on the device)");
+  HIPCHK(hipSetDevice(c.device));   // the communicator binds to the calling thread's current device
   c.tr.reset(new RcclTransport(nranks, rank, uid));
   c.dd_on = true; c.P = nranks; c.rk = rank; c.geom_dirty = true;
   return 0;
