@@ -231,12 +231,13 @@ __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R
       int4 im = img4[i];
       R* p = &x.x; int* ip = &im.x;
       int c[3];
+      bool moved = false;   // folded back into the box: only then position and image counters are written back
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         R s = floor_r(p[d] * box.invL[d]);
-        if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; }
-        if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; }
-        if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; }
+        if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; moved = true; }
+        if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; moved = true; }
+        if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; moved = true; }
         int cc = (int)(p[d] * box.cell_inv[d]);
         int ncd = (d == 2 && box.zghost) ? box.nzg : (box.nc[d] > 0 ? box.nc[d] : 1);
         cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
@@ -252,7 +253,7 @@ __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R
         else if (gz == gd) dir = -1;
         else { ctl->mig_error = 1; c[2] = 1; }   // moved by more than one layer: impossible within skin/2
       }
-      x4[i] = x; img4[i] = im;
+      if (moved) { x4[i] = x; img4[i] = im; }
       if (dir) {
         const MigBuf<R>& mb = dir < 0 ? mdn : mup;
         const int k = atomicAdd(mb.count, 1);
