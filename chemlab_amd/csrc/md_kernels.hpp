@@ -378,27 +378,45 @@ __global__ __launch_bounds__(256) void k_place(int i0, int n, const int* __restr
 template <typename R>
 __device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start, const int* perm, const Vec4<R>* x4, const Vec4<R>* v4,
                                                 const int* tag, const int4* img4, Vec4<R>* x4o, Vec4<R>* v4o, int* tago, int4* img4o) {
-  const int l = lane_id();
+  // Two cells per wave (one per half-wave, width-32 shuffles) while both have <= 32 members -- the mean
+  // occupancy is ~18 -- otherwise one cell per wave / the global-memory ranking for crowded cells.
+  const int l = lane_id(), hl = l & 31, half = l >> 5;
   const int nw = gridDim.x * (blockDim.x >> 6);
-  for (int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < ncell; c += nw) {
-    const int s = cell_start[c], cnt = cell_start[c + 1] - s;
-    if (cnt <= 64) {
+  for (int c0 = 2 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); c0 < ncell; c0 += 2 * nw) {
+    const int s0 = cell_start[c0], s1 = cell_start[c0 + 1], s2 = c0 + 1 < ncell ? cell_start[c0 + 2] : s1;
+    const int cnt0 = s1 - s0, cnt1 = s2 - s1;
+    if (cnt0 <= 32 && cnt1 <= 32) {
+      const int s = half ? s1 : s0, cnt = half ? cnt1 : cnt0, cmax = cnt0 > cnt1 ? cnt0 : cnt1;
       int pi = 0, tg = 0x7fffffff;
-      if (l < cnt) { pi = perm[s + l]; tg = tag[pi]; }
+      if (hl < cnt) { pi = perm[s + hl]; tg = tag[pi]; }
       int rank = 0;
-      for (int k = 0; k < cnt; ++k) { const int tk = __shfl(tg, k); rank += (tk < tg) ? 1 : 0; }
-      if (l < cnt) {
+      for (int k = 0; k < cmax; ++k) { const int tk = __shfl(tg, k, 32); rank += (k < cnt && tk < tg) ? 1 : 0; }
+      if (hl < cnt) {
         const int dst = s + rank;
         x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
       }
-    } else {
-      // crowded cell: each lane ranks its members against all others through global memory
-      for (int a = l; a < cnt; a += 64) {
-        const int pi = perm[s + a], tg = tag[pi];
+      continue;
+    }
+    for (int cc = c0; cc < c0 + 2 && cc < ncell; ++cc) {
+      const int s = cell_start[cc], cnt = cell_start[cc + 1] - s;
+      if (cnt <= 64) {
+        int pi = 0, tg = 0x7fffffff;
+        if (l < cnt) { pi = perm[s + l]; tg = tag[pi]; }
         int rank = 0;
-        for (int k = 0; k < cnt; ++k) rank += (tag[perm[s + k]] < tg) ? 1 : 0;
-        const int dst = s + rank;
-        x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+        for (int k = 0; k < cnt; ++k) { const int tk = __shfl(tg, k); rank += (tk < tg) ? 1 : 0; }
+        if (l < cnt) {
+          const int dst = s + rank;
+          x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+        }
+      } else {
+        // crowded cell: each lane ranks its members against all others through global memory
+        for (int a = l; a < cnt; a += 64) {
+          const int pi = perm[s + a], tg = tag[pi];
+          int rank = 0;
+          for (int k = 0; k < cnt; ++k) rank += (tag[perm[s + k]] < tg) ? 1 : 0;
+          const int dst = s + rank;
+          x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+        }
       }
     }
   }
