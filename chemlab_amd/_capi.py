@@ -89,6 +89,7 @@ SIGNATURES = {
     "list_set_params": (_i, [_P, _i, _i, _i, _i, _i, _pd, _i]),
     "get_list": (_i64, [_P, _i, _pi64, _i64]),
     "thermostat_langevin": (_i, [_P, _d, _d, _u64]),
+    "cap_force": (_i, [_P, _d]),
     "reaction_init": (_i, [_P, _i, _i, _i, _u64]),
     "reaction_add": (_i, [_P, C.POINTER(ReactionDesc)]),
     "topology_register": (_i, [_P, _i, _i, _pi32]),

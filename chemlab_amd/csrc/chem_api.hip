@@ -80,7 +80,7 @@ static inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 struct Ctx {
   std::string err;
   int device = 0, prec = 32;
-  double L[3] = {0, 0, 0}, rc = 0, skin = 0, dt = 0;
+  double L[3] = {0, 0, 0}, rc = 0, skin = 0, dt = 0, cap_force = 0;
   HostTopology top;
   std::vector<double> pos0, vel0;  // staged particle data (tag order) until first upload
   int ntypes = 1;
@@ -787,12 +787,15 @@ template <typename R> struct CtxT : Ctx {
   template <int MODE> void launch_integrate(bool with_lang, bool storef, int64_t istep, int phase) {
     const int nb = cdiv(n, 256);
     LangevinP<R> lp = lang_params(istep, phase);
+    // CapForce acts on the freshly evaluated conservative force: every launch that applies the thermostat
+    // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
+    const R cap = (cap_force > 0 && (with_lang || !lang)) ? (R)cap_force : (R)0;
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr);
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
   }
 
   void check_flags() {
@@ -1538,6 +1541,8 @@ int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t se
   return 0;
   API_END(ctx)
 }
+
+int chem_cap_force(chem_ctx* ctx, double max_force) { API_BEGIN CTX.cap_force = max_force > 0 ? max_force : 0; return 0; API_END(ctx) }
 
 int chem_reaction_init(chem_ctx* ctx, int interval, int nearest, int max_per_interval, uint64_t seed) {
   API_BEGIN

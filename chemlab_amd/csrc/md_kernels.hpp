@@ -121,11 +121,15 @@ template <typename R, int MODE, bool LANG, bool STOREF>
 __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
                                                     R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax,
-                                                    const Vec4<R>* __restrict__ x0) {
+                                                    const Vec4<R>* __restrict__ x0, R cap) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   R d2 = 0;
   if (i < n) {
     Vec4<R> v = v4[i], f = f4[i];
+    if (cap > (R)0) {   // CapForce: f4 holds the conservative force of this step (the host passes cap only then)
+      const R f2 = f.x * f.x + f.y * f.y + f.z * f.z;
+      if (f2 > cap * cap) { const R s = cap / sqrt_r(f2); f.x *= s; f.y *= s; f.z *= s; }
+    }
     if (LANG) {
       langevin_force<R>(lp, tag[i], v.w, v.x, v.y, v.z, f.x, f.y, f.z);
       if (STOREF) f4[i] = f;

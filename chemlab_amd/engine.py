@@ -129,6 +129,9 @@ class Engine:
     def thermostat_langevin(self, kT, gamma, seed=0):
         self._ck(self.api.thermostat_langevin(self.ctx, float(kT), float(gamma), int(seed)))
 
+    def cap_force(self, max_force):
+        self._ck(self.api.cap_force(self.ctx, float(max_force)))
+
     def reaction_init(self, interval, nearest=True, max_per_interval=0, seed=0):
         self._ck(self.api.reaction_init(self.ctx, int(interval), 1 if nearest else 0, int(max_per_interval), int(seed)))
 

@@ -554,6 +554,25 @@ class _LangevinThermostat(object):
         self.system.engine.thermostat_langevin(self.temperature, self.gamma, seed)
 
 
+class _CapForce(object):
+    """integrator.CapForce(system, max_force) (start_simulation.py:320-324): conservative force of a particle
+    rescaled to |f| = max_force where it exceeds it, before the thermostat's terms."""
+
+    def __init__(self, system, capForce, particleGroup=None):
+        if particleGroup is not None:
+            raise NotImplementedError("CapForce on a particle group is outside the hot-path scope")
+        if not isinstance(capForce, (int, float)):
+            raise NotImplementedError("CapForce with a Real3D cap is outside the hot-path scope (ChemLab passes a scalar)")
+        self.system = system
+        self.capForce = float(capForce)
+
+    def _connect(self, integrator):
+        self.system.engine.cap_force(self.capForce)
+
+    def disconnect(self):
+        self.system.engine.cap_force(0.0)
+
+
 class _TopologyParticleProperties(object):
     def __init__(self, type=None, mass=None, q=None, **kw):
         self.type, self.mass, self.q = type, mass, q
@@ -730,7 +749,7 @@ integrator = _ns(
     StochasticVelocityRescaling=_unsupported("integrator.StochasticVelocityRescaling"),
     BerendsenThermostat=_unsupported("integrator.BerendsenThermostat"), BerendsenBarostat=_unsupported("integrator.BerendsenBarostat"),
     Isokinetic=_unsupported("integrator.Isokinetic"), LangevinBarostat=_unsupported("integrator.LangevinBarostat"),
-    CapForce=_unsupported("integrator.CapForce"), RestrictReaction=_unsupported("integrator.RestrictReaction"),
+    CapForce=_CapForce, RestrictReaction=_unsupported("integrator.RestrictReaction"),
     DissociationReaction=_unsupported("integrator.DissociationReaction"), ATRPActivator=_unsupported("integrator.ATRPActivator"),
     ReactionCutoffRandom=_unsupported("integrator.ReactionCutoffRandom"), FixDistances=_unsupported("integrator.FixDistances"),
     ChangeInRegion=_unsupported("integrator.ChangeInRegion"), BasicDynamicResolution=_unsupported("integrator.BasicDynamicResolution"),

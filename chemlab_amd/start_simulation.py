@@ -112,6 +112,9 @@ def main(argv=None, hooks=None, quiet=False):
     angles = gromacs_topology.set_angle_interactions(espressopp, system, gt, dynamic_types)
     if gt.dihedrals:
         raise NotImplementedError("[ dihedrals ] from topology files: lowest priority in SURVEY.md 8 (a8); use the C ABI directly")
+    if args.max_force > -1:                               # start_simulation.py:320-324, before the thermostat
+        integrator.addExtension(espressopp.integrator.CapForce(system, args.max_force))
+        log("Cap force to %s" % args.max_force)
     # thermostat (start_simulation.py:329-354)
     temperature = args.temperature * kb
     if args.thermostat == "lv":

@@ -189,6 +189,11 @@ int64_t chem_get_list(chem_ctx* ctx, int list, int64_t* out, int64_t cap_entries
 /* integrator.LangevinThermostat: .temperature (=T*kb), .gamma  start_simulation.py:330-336.
  * gamma<=0 or kT<0 switches it off (thermostat=no, Q6 in SURVEY). */
 int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t seed);
+/* integrator.CapForce(system, max_force), added before the thermostat -- start_simulation.py:320-324
+ * (`max_force`, app_args default -1 = off): after every force evaluation the conservative force of a
+ * particle is rescaled to |f| = max_force where it exceeds it; the thermostat's friction and noise come
+ * on top, uncapped (extension order).  max_force <= 0 switches it off. */
+int chem_cap_force(chem_ctx* ctx, double max_force);
 
 /* ---- reactions ----------------------------------------------------------------------- */
 /* integrator.ChemicalReaction(system, vl, storage, tm, interval) + .nearest_mode

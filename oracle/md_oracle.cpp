@@ -103,6 +103,7 @@ struct Orc {
   std::vector<Vec3> x0;         // positions at the last list build (criterion 1)
   std::vector<std::pair<int32_t, int32_t>> pairs;  // half Verlet list
   int64_t rebuilds = 0, reaction_steps = 0;
+  double cap_force = 0;
   double e_lj = 0, e_tab = 0, virial = 0;
   double e_list[CHEM_MAX_LISTS] = {0};
 };
@@ -303,6 +304,12 @@ static void update_forces(Orc& o, int64_t istep, int phase) {
     o.virial += ff * r2;
   }
   bonded_forces(o);
+  if (o.cap_force > 0) {   // integrator.CapForce, connected before the thermostat (start_simulation.py:320-324)
+    for (int64_t i = 0; i < o.n; ++i) {
+      const double f2 = o.f[i].x * o.f[i].x + o.f[i].y * o.f[i].y + o.f[i].z * o.f[i].z;
+      if (f2 > o.cap_force * o.cap_force) { const double s = o.cap_force / std::sqrt(f2); o.f[i] = s * o.f[i]; }
+    }
+  }
   if (o.lang) {
     for (int64_t i = 0; i < o.n; ++i) {
       uint32_t r[4];
@@ -609,6 +616,7 @@ int64_t orc_get_list(void* c, int list, int64_t* out, int64_t cap) {
   return ne;
 }
 
+int orc_cap_force(void* c, double max_force) { O(c).cap_force = max_force > 0 ? max_force : 0; return 0; }
 int orc_thermostat_langevin(void* c, double kT, double gamma, uint64_t seed) {
   Orc& o = O(c); o.lang = (gamma > 0 && kT >= 0); o.kT = kT; o.gamma = gamma; o.lang_seed = seed; return 0;
 }

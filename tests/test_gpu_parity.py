@@ -742,3 +742,22 @@ def test_dd_eight_slabs_at_bench_size_in_process(make_gpu):
         assert [e[:4] for e in out[r]["ev"]] == [e[:4] for e in ref]
         assert out[r]["reb"] >= 4
     assert rel_err(out[0]["x"], xs) < 1e-4
+
+
+@pytest.mark.parametrize("prec,thermo", [(64, False), (64, True), (32, True)])
+def test_cap_force_matches_oracle(make_gpu, make_oracle, prec, thermo):
+    """SURVEY f-1: integrator.CapForce.  A jittered lattice with a few close contacts, cap well below the
+    largest forces so that it acts on many particles every step; with and without the Langevin terms on top."""
+    spec = W.lj_melt(n=4000, seed=7, jitter=0.16)
+    g, o, _ = both(make_gpu, make_oracle, spec, prec, thermostat=thermo)
+    g.cap_force(40.0); o.cap_force(40.0)
+    g.run(0); o.run(0)
+    fraw = o.get_state("FORCE")
+    if not thermo:
+        assert (np.linalg.norm(fraw, axis=1) > 40.0).sum() > 50   # get_state returns the evaluated (uncapped) force
+    g.run(30); o.run(30)
+    assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < (1e-8 if prec == 64 else 2e-4)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 1e-4)
+    g.cap_force(0.0); o.cap_force(0.0)                            # switched off again
+    g.run(10); o.run(10)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 1e-4)

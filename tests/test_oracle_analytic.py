@@ -136,3 +136,27 @@ def test_typed_list_uses_current_types(make_oracle):
     e.list_add(h, [[1, 2], [2, 3]])
     _, obs = forces_energy(e)
     assert obs["epot_list"][0] == pytest.approx(10.0 * 0.1 ** 2 + 20.0 * 0.1 ** 2, rel=1e-10)
+
+
+def test_cap_force_rescales_conservative_force_only(make_oracle):
+    """integrator.CapForce (start_simulation.py:320-324): |f| capped at max_force, direction kept; the cap is
+    applied before the thermostat, so with gamma > 0 the friction term comes on top of the capped force."""
+    import numpy as np
+    spec = dict(n=2, box=[20.0, 20.0, 20.0], rc=2.5, skin=0.3, dt=0.001, ids=np.array([1, 2]), types=np.zeros(2, np.int32),
+                pos=np.array([[5.0, 5.0, 5.0], [5.9, 5.0, 5.0]]), vel=np.array([[1.0, 0, 0], [0, 0, 0]]), mass=np.ones(2),
+                lj=[(0, 0, 1.0, 1.0, 2.5)], kT=1.0, gamma=0.0, seed=1)
+    from chemlab_amd import workloads as W
+    o = make_oracle(); W.apply(spec, o, thermostat=False)
+    o.run(0)
+    f0 = o.get_state("FORCE")
+    mag = np.linalg.norm(f0[0])
+    assert mag > 50                                          # r = 0.9 sigma: strongly repulsive
+    o2 = make_oracle(); W.apply(spec, o2, thermostat=False); o2.cap_force(10.0)
+    o2.run(0)
+    f1 = o2.get_state("FORCE")
+    assert np.allclose(np.linalg.norm(f1, axis=1), 10.0)
+    assert np.allclose(f1 / 10.0, f0 / mag)
+    # one step: dv = dt * f_capped / m (both half kicks use capped forces of similar size)
+    o2.run(1)
+    v = o2.get_state("VEL")
+    assert abs((v[0, 0] - 1.0) + 0.001 * 10.0) < 1e-3 * 0.001 * 10.0 + 1e-9
