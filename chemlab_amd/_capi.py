@@ -23,7 +23,7 @@ CHEM_MAX_POT_PARAMS = 6
 OK, EINVAL, ENOSPC, EDEVICE, ESTATE, ENOTIMPL, ECOMM = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_F64 = 32, 64
 
-POT = dict(HARMONIC=1, FENE=2, ANG_HARMONIC=10, ANG_COSINE=11, DIH_NCOS=20, DIH_RB=21)
+POT = dict(HARMONIC=1, FENE=2, TABULATED=3, ANG_HARMONIC=10, ANG_COSINE=11, DIH_NCOS=20, DIH_RB=21)
 STATE = dict(POS=1, VEL=2, FORCE=3, TYPE=4, STATE=5, RESID=6, MASS=7, ID=8, IMAGE=9, MOLID=10,
              POS_UNFOLDED=11)
 
@@ -90,6 +90,7 @@ SIGNATURES = {
     "get_list": (_i64, [_P, _i, _pi64, _i64]),
     "thermostat_langevin": (_i, [_P, _d, _d, _u64]),
     "cap_force": (_i, [_P, _d]),
+    "table_create": (_i, [_P, C.c_int64, _d, _d, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "reaction_init": (_i, [_P, _i, _i, _i, _u64]),
     "reaction_add": (_i, [_P, C.POINTER(ReactionDesc)]),
     "topology_register": (_i, [_P, _i, _i, _pi32]),

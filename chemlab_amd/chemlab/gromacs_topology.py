@@ -170,7 +170,7 @@ def _type_params(table, types_, default=None):
     return node
 
 
-def set_bonded_interactions(espressopp, system, gt, dynamic_type_ids=()):
+def set_bonded_interactions(espressopp, system, gt, dynamic_type_ids=(), table_dir="."):
     """[ bonds ] -> FixedPairList interactions (:902-1061).  Entries whose type pair can change through
     a reaction go to ONE Types list (parameters by current types); the rest are grouped by parameters."""
     groups, dyn = collections.OrderedDict(), []
@@ -194,11 +194,20 @@ def set_bonded_interactions(espressopp, system, gt, dynamic_type_ids=()):
             return espressopp.interaction.Harmonic(K=p[1] / 2.0, r0=p[0])       # K = k_gmx / 2 (:918)
         if func == 7:
             return espressopp.interaction.FENE(K=p[1], r0=0.0, rMax=p[0])
+        if func == 8:                                                           # table_b<N>.xvg -> .pot if missing (:919-925)
+            pot = os.path.join(table_dir, "table_b%d.pot" % int(p[0]))
+            if not os.path.exists(pot):
+                tables.convert_table(os.path.join(table_dir, "table_b%d.xvg" % int(p[0])), pot)
+            return espressopp.interaction.Tabulated(itype=1, filename=pot)
         raise NotImplementedError("bond func %d is outside the hot-path scope" % func)
     for k, ((func, p), bl) in enumerate(groups.items()):
         fpl = espressopp.FixedPairList(system.storage)
         fpl.addBonds(bl)
-        inter = (espressopp.interaction.FixedPairListHarmonic if func == 1 else espressopp.interaction.FixedPairListFENE)(system, fpl, pot_of(func, p))
+        cls = {1: espressopp.interaction.FixedPairListHarmonic, 7: espressopp.interaction.FixedPairListFENE,
+               8: espressopp.interaction.FixedPairListTabulated}.get(func)
+        if cls is None:
+            raise NotImplementedError("bond func %d is outside the hot-path scope" % func)
+        inter = cls(system, fpl, pot_of(func, p))
         system.addInteraction(inter, "bond_%d" % k)
         out["bond_%d" % k] = (fpl, inter)
     if dyn:

@@ -470,7 +470,21 @@ template <typename R> struct CtxT : Ctx {
     top.build_bonded(hs, he, hp);
     upload_bonded_from(hs, he, hp);
   }
+  DBuf<double2> btab_rows; DBuf<double4> btab_info; size_t btab_uploaded = 0;
+  BTab btab_view() const { return BTab{btab_rows.p, btab_info.p}; }
+  void upload_bond_tables() {
+    if (btab_uploaded == top.btables.size()) return;
+    std::vector<double2> rows; std::vector<double4> info;
+    for (const HostBondTable& t : top.btables) {
+      info.push_back(make_double4((double)rows.size(), (double)t.e.size(), t.r0, 1.0 / t.dr));
+      for (size_t k = 0; k < t.e.size(); ++k) rows.push_back(make_double2(t.e[k], t.f[k]));
+    }
+    btab_rows.upload(rows, stream); btab_info.upload(info, stream);
+    HIPCHK(hipStreamSynchronize(stream));
+    btab_uploaded = top.btables.size();
+  }
   template <class VI, class VE> void upload_bonded_from(const VI& hs, const VE& he, const std::vector<HBondedParam>& hp) {
+    upload_bond_tables();
     static_assert(sizeof(HBondedEntry) == sizeof(BondedEntry) && sizeof(HBondedParam) == sizeof(BondedParam), "layout");
     bstart.alloc(hs.size()); bent.alloc(he.size()); bpar.alloc(hp.size());
     HIPCHK(hipMemcpyAsync(bstart.p, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -771,10 +785,10 @@ template <typename R> struct CtxT : Ctx {
         hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
         bwork_dirty = false;
       }
-      hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0);
+      hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
     } else if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
-                         bpar.p, boxd, elist.p, ctl.p);
+                         bpar.p, boxd, elist.p, ctl.p, btab_view());
     pair_guard = 0;
   }
 
@@ -1245,7 +1259,7 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipMemsetAsync(elist.p, 0, sizeof(double) * CHEM_MAX_LISTS, stream));
     if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, true>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, x4o.p, tag.p, rtag.p, bstart.p, bent.p,
-                         bpar.p, boxd, elist.p, ctl.p);
+                         bpar.p, boxd, elist.p, ctl.p, btab_view());
     const int nkb = cdiv(n, 256);
     hipLaunchKernelGGL(k_kinetic<R>, dim3(nkb), dim3(256), 0, stream, G, n, v4.p, ekout.p);
     std::vector<double> he, hk, hl;
@@ -1473,7 +1487,7 @@ int chem_nb_table(chem_ctx* ctx, int t1, int t2, int64_t nrow, double r0, double
 int chem_list_create(chem_ctx* ctx, int arity, int kind, int by_types) {
   API_BEGIN
   REQUIRE(arity >= 2 && arity <= 4, CHEM_EINVAL, "list arity must be 2, 3 or 4");
-  const bool ok = (arity == 2 && (kind == CHEM_POT_HARMONIC || kind == CHEM_POT_FENE)) ||
+  const bool ok = (arity == 2 && (kind == CHEM_POT_HARMONIC || kind == CHEM_POT_FENE || kind == CHEM_POT_TABULATED)) ||
                   (arity == 3 && (kind == CHEM_POT_ANG_HARMONIC || kind == CHEM_POT_ANG_COSINE)) ||
                   (arity == 4 && (kind == CHEM_POT_DIH_NCOS || kind == CHEM_POT_DIH_RB));
   REQUIRE(ok, CHEM_ENOTIMPL, "potential kind not supported for this arity");
@@ -1481,6 +1495,16 @@ int chem_list_create(chem_ctx* ctx, int arity, int kind, int by_types) {
   HostList l; l.arity = arity; l.kind = kind; l.by_types = by_types ? 1 : 0;
   CTX.top.lists.push_back(std::move(l));
   return (int)CTX.top.lists.size() - 1;
+  API_END(ctx)
+}
+
+int chem_table_create(chem_ctx* ctx, int64_t nrow, double r0, double dr, const double* e, const double* f) {
+  API_BEGIN
+  REQUIRE(nrow >= 2 && dr > 0 && e && f, CHEM_EINVAL, "table_create: need >= 2 rows, dr > 0");
+  HostBondTable t; t.r0 = r0; t.dr = dr; t.e.assign(e, e + nrow); t.f.assign(f, f + nrow);
+  CTX.top.btables.push_back(std::move(t));
+  CTX.bonded_dirty = true;
+  return (int)CTX.top.btables.size() - 1;
   API_END(ctx)
 }
 
@@ -1508,6 +1532,8 @@ int chem_list_set_params(chem_ctx* ctx, int list, int t1, int t2, int t3, int t4
   API_BEGIN
   HostTopology& t = CTX.top;
   REQUIRE(list >= 0 && list < (int)t.lists.size() && p && np >= 1 && np <= CHEM_MAX_POT_PARAMS, CHEM_EINVAL, "list_set_params");
+  if (t.lists[list].kind == CHEM_POT_TABULATED)
+    REQUIRE(p[0] >= 0 && p[0] < (double)t.btables.size() && p[0] == (double)(int)p[0], CHEM_EINVAL, "tabulated bonds: parameter must be a handle from chem_table_create");
   HostList& l = t.lists[list];
   std::array<double, CHEM_MAX_POT_PARAMS> v{};
   std::copy(p, p + np, v.begin());

@@ -107,8 +107,11 @@ struct HostPairPot {
 struct HBondedParam { int kind, list, arity, pad; double p[CHEM_MAX_POT_PARAMS]; };
 struct HBondedEntry { int t0, t1, t2, meta; };
 
+struct HostBondTable { double r0 = 0, dr = 1; std::vector<double> e, f; };
+
 struct HostTopology {
   int64_t n = 0;
+  std::vector<HostBondTable> btables;   // chem_table_create registry (tabulated bonds)
   std::vector<int64_t> id;  // tag -> external id (ascending)
   bool contiguous = true;
   int64_t id0 = 0;

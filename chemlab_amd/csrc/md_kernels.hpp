@@ -1421,10 +1421,13 @@ __device__ __forceinline__ D3 minimgD(const BoxD& b, D3 d) {
 }
 template <typename R> __device__ __forceinline__ D3 posD(const Vec4<R>& v) { return {(double)v.x, (double)v.y, (double)v.z}; }
 
+// bond tables (chem_table_create): rows = (e, f) pairs of all tables back to back, info[h] = (first row, rows, r0, 1/dr)
+struct BTab { const double2* rows; const double4* info; };
+
 // one bonded term seen from member `me` of the tuple (j0..j3 = particle indices of the tuple in order)
 template <typename R, bool ENERGY>
 __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me, const int j0, const int j1, const int j2, const int j3,
-                                            const Vec4<R>* __restrict__ x4, const BoxD& box, D3& f, double* __restrict__ elist, DevCtl* ctl) {
+                                            const Vec4<R>* __restrict__ x4, const BoxD& box, D3& f, double* __restrict__ elist, DevCtl* ctl, const BTab& bt) {
     const double* p = bp.p;
     double u = 0;
     if (bp.arity == 2) {
@@ -1436,6 +1439,17 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
       double ff = 0;
       if (bp.kind == CHEM_POT_HARMONIC) { const double dr = r - p[1]; u = p[0] * dr * dr; ff = -2.0 * p[0] * dr / r; }
       else if (bp.kind == CHEM_POT_FENE) { const double dr = r - p[1], q = dr / p[2], den = 1.0 - q * q; u = -0.5 * p[0] * p[2] * p[2] * log(den); ff = -p[0] * dr / den / r; }
+      else if (bp.kind == CHEM_POT_TABULATED) {   // Tabulated(itype=1): linear interpolation of e(r), f(r); end rows beyond the grid
+        const double4 ti = bt.info[(int)p[0]];
+        const double2* row = bt.rows + (size_t)ti.x;
+        const int nrow = (int)ti.y;
+        const double t = (r - ti.z) * ti.w;
+        double fv;
+        if (t <= 0) { u = row[0].x; fv = row[0].y; }
+        else if (t >= (double)(nrow - 1)) { u = row[nrow - 1].x; fv = row[nrow - 1].y; }
+        else { const int k = (int)t; const double w = t - (double)k; const double2 a = row[k], b = row[k + 1]; u = a.x + w * (b.x - a.x); fv = a.y + w * (b.y - a.y); }
+        ff = fv / r;
+      }
       const double sgn = me == 0 ? 1.0 : -1.0;
       f = f + (sgn * ff) * d;
     } else if (bp.arity == 3) {
@@ -1487,7 +1501,7 @@ template <typename R, bool ENERGY>
 __global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
                                                 const int* __restrict__ tag, const int* __restrict__ rtag,
                                                 const int* __restrict__ bstart, const BondedEntry* __restrict__ bent,
-                                                const BondedParam* __restrict__ bpar, BoxD box, double* __restrict__ elist, DevCtl* ctl) {
+                                                const BondedParam* __restrict__ bpar, BoxD box, double* __restrict__ elist, DevCtl* ctl, BTab bt) {
   const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= i0 + n) return;
   const int tg = tag[i];
@@ -1502,7 +1516,7 @@ __global__ __launch_bounds__(256) void k_bonded(int i0, int n, const Vec4<R>* __
     const int j0 = rtag[be.t0], j1 = rtag[be.t1], j2 = ar > 2 ? rtag[be.t2] : 0;
     int j3 = 0;
     if (ar == 4) { j3 = rtag[bent[e + 1].t0]; ++e; }   // quadruples occupy two consecutive entries: (t0,t1,t2,meta),(t3,-,-,-)
-    bonded_term<R, ENERGY>(bp, me, j0, j1, j2, j3, x4, box, f, elist, ctl);
+    bonded_term<R, ENERGY>(bp, me, j0, j1, j2, j3, x4, box, f, elist, ctl, bt);
   }
   Vec4<R> fo = f4[i];
   fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;
@@ -1560,7 +1574,7 @@ __global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* _
 
 template <typename R>
 __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int4* __restrict__ bwork, const int4* __restrict__ bj,
-                                                     const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl, int guard) {
+                                                     const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl, int guard, BTab bt) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= ctl->bwork_count || (guard && ctl->need_rebuild)) return;
   const int4 wk = bwork[k];
@@ -1572,7 +1586,7 @@ __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__
     const BondedParam& bp = bpar[slot];
     int j3 = 0;
     if (bp.arity == 4) { j3 = bj[e + 1].x; ++e; }
-    bonded_term<R, false>(bp, me, jj.x, jj.y, bp.arity > 2 ? jj.z : 0, j3, x4, box, f, nullptr, ctl);
+    bonded_term<R, false>(bp, me, jj.x, jj.y, bp.arity > 2 ? jj.z : 0, j3, x4, box, f, nullptr, ctl, bt);
   }
   Vec4<R> fo = f4[wk.x];
   fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;

@@ -129,6 +129,12 @@ class Engine:
     def thermostat_langevin(self, kT, gamma, seed=0):
         self._ck(self.api.thermostat_langevin(self.ctx, float(kT), float(gamma), int(seed)))
 
+    def table_create(self, r0, dr, e, f):
+        """Bond table (rows of a .pot file); returns the handle to pass as list_set_params(h, [handle])."""
+        e = np.ascontiguousarray(e, dtype=np.float64); f = np.ascontiguousarray(f, dtype=np.float64)
+        assert e.shape == f.shape
+        return self._ck(self.api.table_create(self.ctx, e.shape[0], float(r0), float(dr), _ptr(e, C.c_double), _ptr(f, C.c_double)))
+
     def cap_force(self, max_force):
         self._ck(self.api.cap_force(self.ctx, float(max_force)))
 

@@ -416,25 +416,38 @@ class _VerletListTabulated(_VerletListInteraction):
 class _FixedListInteraction(object):
     by_types = False
 
+    def _kp(self, pot):
+        """(kind, parameter list) of a potential object; a Tabulated bond potential (func 8,
+        gromacs_topology.py:919-925) registers its rows once per engine and passes the table handle."""
+        if isinstance(pot, _Tabulated):
+            eng = self.system.engine
+            cache = pot.__dict__.setdefault("_handles", {})
+            if id(eng) not in cache:
+                cache[id(eng)] = eng.table_create(pot.r0, pot.dr, pot.e, pot.f)
+            return "TABULATED", [float(cache[id(eng)])]
+        return pot.kind, pot.params()
+
     def __init__(self, system, flist, potential=None):
         self.system, self.flist = system, flist
         self.potential = potential
         self._typed = {}
         if potential is not None:
-            h = flist._bind(potential.kind, False)
-            system.engine.list_set_params(h, potential.params())
+            kind, par = self._kp(potential)
+            h = flist._bind(kind, False)
+            system.engine.list_set_params(h, par)
 
     def setPotential(self, *args):
         pot = args[-1]
         types = tuple(int(t) for t in args[:-1])
+        kind, par = self._kp(pot)
         if not self.by_types:
             self.potential = pot
-            h = self.flist._bind(pot.kind, False)
-            self.system.engine.list_set_params(h, pot.params())
+            h = self.flist._bind(kind, False)
+            self.system.engine.list_set_params(h, par)
             return
-        h = self.flist._bind(pot.kind, True)
+        h = self.flist._bind(kind, True)
         self._typed[types] = pot
-        self.system.engine.list_set_params(h, pot.params(), types=types)
+        self.system.engine.list_set_params(h, par, types=types)
 
     def getFixedPairList(self):
         return self.flist
@@ -469,8 +482,7 @@ interaction = _ns(
     FENELennardJones=_unsupported("interaction.FENELennardJones"), CoulombTruncated=_unsupported("interaction.CoulombTruncated"),
     VerletListCoulombTruncated=_unsupported("interaction.VerletListCoulombTruncated"),
     TabulatedAngular=_unsupported("interaction.TabulatedAngular"), TabulatedDihedral=_unsupported("interaction.TabulatedDihedral"),
-    FixedPairListTabulated=_unsupported("interaction.FixedPairListTabulated"),
-    FixedPairListTypesTabulated=_unsupported("interaction.FixedPairListTypesTabulated"),
+    FixedPairListTabulated=_FixedListInteraction, FixedPairListTypesTabulated=_FixedListTypesInteraction,
     FixedTripleListTabulatedAngular=_unsupported("interaction.FixedTripleListTabulatedAngular"),
     FixedPairListLambdaHarmonic=_unsupported("interaction.FixedPairListLambdaHarmonic"),
     VerletListDynamicResolutionLennardJones=_unsupported("interaction.VerletListDynamicResolutionLennardJones"),

@@ -108,7 +108,8 @@ def main(argv=None, hooks=None, quiet=False):
     table_groups = args.table_groups.split(",") if args.table_groups else []
     gromacs_topology.set_nonbonded_interactions(espressopp, system, gt, verletlist, lj_cutoff, tab_cutoff=cg_cutoff, tables_=table_groups,
                                                 table_dir=os.path.dirname(os.path.abspath(args.top)))
-    bonded = gromacs_topology.set_bonded_interactions(espressopp, system, gt, dynamic_types)
+    bonded = gromacs_topology.set_bonded_interactions(espressopp, system, gt, dynamic_types,
+                                                      table_dir=os.path.dirname(os.path.abspath(args.top)))
     angles = gromacs_topology.set_angle_interactions(espressopp, system, gt, dynamic_types)
     if gt.dihedrals:
         raise NotImplementedError("[ dihedrals ] from topology files: lowest priority in SURVEY.md 8 (a8); use the C ABI directly")

@@ -53,6 +53,7 @@ extern "C" {
  */
 #define CHEM_POT_HARMONIC      1
 #define CHEM_POT_FENE          2
+#define CHEM_POT_TABULATED     3   /* bonds: params = { table handle } from chem_table_create */
 #define CHEM_POT_ANG_HARMONIC 10
 #define CHEM_POT_ANG_COSINE   11
 #define CHEM_POT_DIH_NCOS     20
@@ -177,6 +178,11 @@ int chem_nb_table(chem_ctx* ctx, int t1, int t2, int64_t nrow, double r0, double
  * by_types!=0 -> the "Types" variant: parameters selected per entry from the CURRENT
  * particle types (gromacs_topology.py:969-981).  Returns the list handle. */
 int chem_list_create(chem_ctx* ctx, int arity, int potential_kind, int by_types);
+/* interaction.Tabulated(itype=1, filename=table_b<N>.pot) for bonds, `[ bonds ]`/`[ bondtypes ]` func 8
+ * gromacs_topology.py:919-925,953,961: rows `r e f` on a uniform grid (tools/convert_gromacs2espp.py), linear
+ * interpolation of e(r) and f(r), F_ij = f(r)/r * r_ij, first/last row beyond the grid.  Returns a table
+ * handle >= 0 that is passed as the single parameter of a CHEM_POT_TABULATED list (plain or per type pair). */
+int chem_table_create(chem_ctx* ctx, int64_t nrow, double r0, double dr, const double* e, const double* f);
 /* addBonds/addTriples/addQuadruples: ids is n*arity particle ids */
 int chem_list_add(chem_ctx* ctx, int list, int64_t n, const int64_t* ids);
 /* plain list: t1..t4 ignored (pass -1); Types list: setPotential(type1,type2[,type3[,type4]],pot) */

@@ -104,6 +104,8 @@ struct Orc {
   std::vector<std::pair<int32_t, int32_t>> pairs;  // half Verlet list
   int64_t rebuilds = 0, reaction_steps = 0;
   double cap_force = 0;
+  struct BTable { double r0, dr; std::vector<double> e, f; };
+  std::vector<BTable> btables;   // chem_table_create registry (tabulated bonds)
   double e_lj = 0, e_tab = 0, virial = 0;
   double e_list[CHEM_MAX_LISTS] = {0};
 };
@@ -243,6 +245,15 @@ static void bonded_forces(Orc& o) {
           double dr = r - p[1], q = dr / p[2], den = 1.0 - q * q;
           u = -0.5 * p[0] * p[2] * p[2] * std::log(den);
           ff = -p[0] * dr / den / r;
+        } else if (l.kind == CHEM_POT_TABULATED) {   // Tabulated(itype=1): linear interpolation, gromacs_topology.py:919-925
+          const Orc::BTable& tb = o.btables[(size_t)p[0]];
+          const int64_t nrow = (int64_t)tb.e.size();
+          const double t = (r - tb.r0) / tb.dr;
+          double fv;
+          if (t <= 0) { u = tb.e[0]; fv = tb.f[0]; }
+          else if (t >= (double)(nrow - 1)) { u = tb.e[nrow - 1]; fv = tb.f[nrow - 1]; }
+          else { const int64_t k = (int64_t)t; const double w = t - (double)k; u = tb.e[k] + w * (tb.e[k + 1] - tb.e[k]); fv = tb.f[k] + w * (tb.f[k + 1] - tb.f[k]); }
+          ff = fv / r;
         }
         o.f[t[0]] = o.f[t[0]] + ff * d; o.f[t[1]] = o.f[t[1]] - ff * d; etot += u;
       } else if (l.arity == 3) {
@@ -616,6 +627,13 @@ int64_t orc_get_list(void* c, int list, int64_t* out, int64_t cap) {
   return ne;
 }
 
+int orc_table_create(void* c, int64_t nrow, double r0, double dr, const double* e, const double* f) {
+  Orc& o = O(c);
+  if (nrow < 2 || !(dr > 0) || !e || !f) FAIL(CHEM_EINVAL, "table_create");
+  Orc::BTable t; t.r0 = r0; t.dr = dr; t.e.assign(e, e + nrow); t.f.assign(f, f + nrow);
+  o.btables.push_back(std::move(t));
+  return (int)o.btables.size() - 1;
+}
 int orc_cap_force(void* c, double max_force) { O(c).cap_force = max_force > 0 ? max_force : 0; return 0; }
 int orc_thermostat_langevin(void* c, double kT, double gamma, uint64_t seed) {
   Orc& o = O(c); o.lang = (gamma > 0 && kT >= 0); o.kT = kT; o.gamma = gamma; o.lang_seed = seed; return 0;

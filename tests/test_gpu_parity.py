@@ -761,3 +761,33 @@ def test_cap_force_matches_oracle(make_gpu, make_oracle, prec, thermo):
     g.cap_force(0.0); o.cap_force(0.0)                            # switched off again
     g.run(10); o.run(10)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 1e-4)
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_tabulated_bonds_match_oracle(make_gpu, make_oracle, prec):
+    """SURVEY f-1: bond func 8 (Tabulated(itype=1) on a FixedPairList).  The polymer melt with its harmonic bonds
+    replaced by a table of a stiff anharmonic bond (two table handles: a plain list and a typed list share the
+    registry), forces, energies and a short trajectory against the oracle."""
+    spec = W.polymer_melt(n_chains=128, chain_len=32, seed=3)
+    bonds = spec["lists"][0]["ids"]
+    spec["lists"] = spec["lists"][1:]                                  # keep the angles
+    dr = 0.001
+    r = dr * np.arange(1, 2001)
+    e = 2.0e4 * (r - 0.7) ** 2 + 1.0e5 * (r - 0.7) ** 4
+    f = -(4.0e4 * (r - 0.7) + 4.0e5 * (r - 0.7) ** 3)
+    g, o, _ = both(make_gpu, make_oracle, spec, prec, thermostat=False)
+    for eng in (g, o):
+        t0 = eng.table_create(r[0], dr, e, f)
+        t1 = eng.table_create(r[0], dr, 0.5 * e, 0.5 * f)
+        h = eng.list_create(2, "TABULATED"); eng.list_set_params(h, [t0]); eng.list_add(h, bonds[::2])
+        ht = eng.list_create(2, "TABULATED", True); eng.list_set_params(ht, [t1], types=(0, 0)); eng.list_add(ht, bonds[1::2])
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < (1e-10 if prec == 64 else 5e-4)
+    og, oo = g.observe(), o.observe()
+    assert np.allclose(og["epot_list"][:3], oo["epot_list"][:3], rtol=1e-10 if prec == 64 else 1e-4)
+    assert oo["epot_list"][1] > 0 and oo["epot_list"][2] > 0
+    g.run(25); o.run(25)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-8 if prec == 64 else 1e-4)
+    from chemlab_amd.engine import ChemError
+    with pytest.raises(ChemError):
+        g.list_set_params(h, [7.0])                                     # not a table handle
