@@ -224,7 +224,7 @@ def set_bonded_interactions(espressopp, system, gt, dynamic_type_ids=(), table_d
     return out
 
 
-def set_angle_interactions(espressopp, system, gt, dynamic_type_ids=()):
+def set_angle_interactions(espressopp, system, gt, dynamic_type_ids=(), table_dir="."):
     """[ angles ] -> FixedTripleList interactions (:1069-1176): func 1 AngularHarmonic(K=k/2, theta0 rad),
     func 11 Cosine(K, theta0 rad)."""
     groups, dyn = collections.OrderedDict(), []
@@ -243,12 +243,20 @@ def set_angle_interactions(espressopp, system, gt, dynamic_type_ids=()):
             return espressopp.interaction.AngularHarmonic(K=p[1] / 2.0, theta0=p[0] * math.pi / 180.0)
         if func == 11:
             return espressopp.interaction.Cosine(K=p[1], theta0=p[0] * math.pi / 180.0)
+        if func == 8:                                                           # table_a<N>.xvg (degrees) -> .pot (radians) (:1074-1080)
+            pot = os.path.join(table_dir, "table_a%d.pot" % int(p[0]))
+            if not os.path.exists(pot):
+                tables.convert_table(os.path.join(table_dir, "table_a%d.xvg" % int(p[0])), pot)
+            return espressopp.interaction.TabulatedAngular(itype=1, filename=pot)
         raise NotImplementedError("angle func %d is outside the hot-path scope" % func)
     out = {}
     for k, ((func, p), tl) in enumerate(groups.items()):
         ftl = espressopp.FixedTripleList(system.storage)
         ftl.addTriples(tl)
-        cls = espressopp.interaction.FixedTripleListAngularHarmonic if func == 1 else espressopp.interaction.FixedTripleListCosine
+        cls = {1: espressopp.interaction.FixedTripleListAngularHarmonic, 11: espressopp.interaction.FixedTripleListCosine,
+               8: espressopp.interaction.FixedTripleListTabulatedAngular}.get(func)
+        if cls is None:
+            raise NotImplementedError("angle func %d is outside the hot-path scope" % func)
         inter = cls(system, ftl, pot_of(func, p))
         system.addInteraction(inter, "angle_%d" % k)
         out["angle_%d" % k] = (ftl, inter)

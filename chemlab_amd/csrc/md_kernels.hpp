@@ -1465,6 +1465,17 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
       double dU = 0;
       if (bp.kind == CHEM_POT_ANG_HARMONIC) { const double d = th - p[1]; u = p[0] * d * d; dU = 2.0 * p[0] * d; }
       else if (bp.kind == CHEM_POT_ANG_COSINE) { u = p[0] * (1.0 + cos(th - p[1])); dU = -p[0] * sin(th - p[1]); }
+      else if (bp.kind == CHEM_POT_ANG_TABULATED) {   // TabulatedAngular(itype=1): U(theta), -dU/dtheta on a uniform grid in radians
+        const double4 ti = bt.info[(int)p[0]];
+        const double2* row = bt.rows + (size_t)ti.x;
+        const int nrow = (int)ti.y;
+        const double t = (th - ti.z) * ti.w;
+        double fv;
+        if (t <= 0) { u = row[0].x; fv = row[0].y; }
+        else if (t >= (double)(nrow - 1)) { u = row[nrow - 1].x; fv = row[nrow - 1].y; }
+        else { const int k = (int)t; const double w = t - (double)k; const double2 a = row[k], b = row[k + 1]; u = a.x + w * (b.x - a.x); fv = a.y + w * (b.y - a.y); }
+        dU = -fv;
+      }
       const double a = dU / s;
       const D3 fi = a * ((1.0 / (n1 * n2)) * r2 - (c / (n1 * n1)) * r1);
       const D3 fk = a * ((1.0 / (n1 * n2)) * r1 - (c / (n2 * n2)) * r2);

@@ -324,6 +324,10 @@ class _Tabulated(_Pot):
         self.r0, self.dr = float(self.r[0]), float(self.r[1] - self.r[0])
 
 
+class _TabulatedAngular(_Tabulated):
+    """interaction.TabulatedAngular(itype, filename): rows `theta U -dU/dtheta` (radians) of a table_a<N>.pot file."""
+
+
 class _Harmonic(_Pot):
     kind = "HARMONIC"
 
@@ -420,11 +424,12 @@ class _FixedListInteraction(object):
         """(kind, parameter list) of a potential object; a Tabulated bond potential (func 8,
         gromacs_topology.py:919-925) registers its rows once per engine and passes the table handle."""
         if isinstance(pot, _Tabulated):
+            kind = "ANG_TABULATED" if isinstance(pot, _TabulatedAngular) else "TABULATED"
             eng = self.system.engine
             cache = pot.__dict__.setdefault("_handles", {})
             if id(eng) not in cache:
                 cache[id(eng)] = eng.table_create(pot.r0, pot.dr, pot.e, pot.f)
-            return "TABULATED", [float(cache[id(eng)])]
+            return kind, [float(cache[id(eng)])]
         return pot.kind, pot.params()
 
     def __init__(self, system, flist, potential=None):
@@ -481,9 +486,9 @@ interaction = _ns(
     # out of scope
     FENELennardJones=_unsupported("interaction.FENELennardJones"), CoulombTruncated=_unsupported("interaction.CoulombTruncated"),
     VerletListCoulombTruncated=_unsupported("interaction.VerletListCoulombTruncated"),
-    TabulatedAngular=_unsupported("interaction.TabulatedAngular"), TabulatedDihedral=_unsupported("interaction.TabulatedDihedral"),
+    TabulatedAngular=_TabulatedAngular, TabulatedDihedral=_unsupported("interaction.TabulatedDihedral"),
     FixedPairListTabulated=_FixedListInteraction, FixedPairListTypesTabulated=_FixedListTypesInteraction,
-    FixedTripleListTabulatedAngular=_unsupported("interaction.FixedTripleListTabulatedAngular"),
+    FixedTripleListTabulatedAngular=_FixedListInteraction, FixedTripleListTypesTabulatedAngular=_FixedListTypesInteraction,
     FixedPairListLambdaHarmonic=_unsupported("interaction.FixedPairListLambdaHarmonic"),
     VerletListDynamicResolutionLennardJones=_unsupported("interaction.VerletListDynamicResolutionLennardJones"),
     MixedTabulated=_unsupported("interaction.MixedTabulated"), MultiTabulated=_unsupported("interaction.MultiTabulated"),

@@ -110,7 +110,8 @@ def main(argv=None, hooks=None, quiet=False):
                                                 table_dir=os.path.dirname(os.path.abspath(args.top)))
     bonded = gromacs_topology.set_bonded_interactions(espressopp, system, gt, dynamic_types,
                                                       table_dir=os.path.dirname(os.path.abspath(args.top)))
-    angles = gromacs_topology.set_angle_interactions(espressopp, system, gt, dynamic_types)
+    angles = gromacs_topology.set_angle_interactions(espressopp, system, gt, dynamic_types,
+                                                     table_dir=os.path.dirname(os.path.abspath(args.top)))
     if gt.dihedrals:
         raise NotImplementedError("[ dihedrals ] from topology files: lowest priority in SURVEY.md 8 (a8); use the C ABI directly")
     if args.max_force > -1:                               # start_simulation.py:320-324, before the thermostat

@@ -56,6 +56,7 @@ extern "C" {
 #define CHEM_POT_TABULATED     3   /* bonds: params = { table handle } from chem_table_create */
 #define CHEM_POT_ANG_HARMONIC 10
 #define CHEM_POT_ANG_COSINE   11
+#define CHEM_POT_ANG_TABULATED 12  /* angles func 8: params = { table handle }, grid in radians, f = -dU/dtheta */
 #define CHEM_POT_DIH_NCOS     20
 #define CHEM_POT_DIH_RB       21
 #define CHEM_MAX_POT_PARAMS    6
@@ -181,7 +182,9 @@ int chem_list_create(chem_ctx* ctx, int arity, int potential_kind, int by_types)
 /* interaction.Tabulated(itype=1, filename=table_b<N>.pot) for bonds, `[ bonds ]`/`[ bondtypes ]` func 8
  * gromacs_topology.py:919-925,953,961: rows `r e f` on a uniform grid (tools/convert_gromacs2espp.py), linear
  * interpolation of e(r) and f(r), F_ij = f(r)/r * r_ij, first/last row beyond the grid.  Returns a table
- * handle >= 0 that is passed as the single parameter of a CHEM_POT_TABULATED list (plain or per type pair). */
+ * handle >= 0 that is passed as the single parameter of a CHEM_POT_TABULATED list (plain or per type pair).
+ * The same registry serves interaction.TabulatedAngular (angles func 8, table_a<N>.pot, gromacs_topology.py:1074-1080):
+ * grid in radians, columns U(theta) and -dU/dtheta, list kind CHEM_POT_ANG_TABULATED. */
 int chem_table_create(chem_ctx* ctx, int64_t nrow, double r0, double dr, const double* e, const double* f);
 /* addBonds/addTriples/addQuadruples: ids is n*arity particle ids */
 int chem_list_add(chem_ctx* ctx, int list, int64_t n, const int64_t* ids);

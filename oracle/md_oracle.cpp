@@ -266,6 +266,16 @@ static void bonded_forces(Orc& o) {
         double u = 0, dU = 0;
         if (l.kind == CHEM_POT_ANG_HARMONIC) { double d = th - p[1]; u = p[0] * d * d; dU = 2.0 * p[0] * d; }
         else if (l.kind == CHEM_POT_ANG_COSINE) { u = p[0] * (1.0 + std::cos(th - p[1])); dU = -p[0] * std::sin(th - p[1]); }
+        else if (l.kind == CHEM_POT_ANG_TABULATED) {   // TabulatedAngular(itype=1): table of U(theta), -dU/dtheta, gromacs_topology.py:1074-1080
+          const Orc::BTable& tb = o.btables[(size_t)p[0]];
+          const int64_t nrow = (int64_t)tb.e.size();
+          const double t = (th - tb.r0) / tb.dr;
+          double fv;
+          if (t <= 0) { u = tb.e[0]; fv = tb.f[0]; }
+          else if (t >= (double)(nrow - 1)) { u = tb.e[nrow - 1]; fv = tb.f[nrow - 1]; }
+          else { const int64_t k = (int64_t)t; const double w = t - (double)k; u = tb.e[k] + w * (tb.e[k + 1] - tb.e[k]); fv = tb.f[k] + w * (tb.f[k + 1] - tb.f[k]); }
+          dU = -fv;
+        }
         double a = dU / s;
         Vec3 fi = a * ((1.0 / (n1 * n2)) * r2 - (c / (n1 * n1)) * r1);
         Vec3 fk = a * ((1.0 / (n1 * n2)) * r1 - (c / (n2 * n2)) * r2);

@@ -791,3 +791,26 @@ def test_tabulated_bonds_match_oracle(make_gpu, make_oracle, prec):
     from chemlab_amd.engine import ChemError
     with pytest.raises(ChemError):
         g.list_set_params(h, [7.0])                                     # not a table handle
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_tabulated_angles_match_oracle(make_gpu, make_oracle, prec):
+    """SURVEY f-1: angle func 8 (TabulatedAngular): the polymer melt with its harmonic angles replaced by a table."""
+    spec = W.polymer_melt(n_chains=128, chain_len=32, seed=4)
+    angles = spec["lists"][1]["ids"]
+    spec["lists"] = spec["lists"][:1]                                  # keep the bonds
+    dth = np.pi / 720
+    th = dth * np.arange(1, 721)
+    th0 = np.deg2rad(119.0)
+    e = 244.0 * (th - th0) ** 2 + 30.0 * (th - th0) ** 4
+    f = -(488.0 * (th - th0) + 120.0 * (th - th0) ** 3)
+    g, o, _ = both(make_gpu, make_oracle, spec, prec, thermostat=False)
+    for eng in (g, o):
+        h = eng.list_create(3, "ANG_TABULATED"); eng.list_set_params(h, [eng.table_create(th[0], dth, e, f)]); eng.list_add(h, angles)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < (1e-10 if prec == 64 else 5e-4)
+    og, oo = g.observe(), o.observe()
+    assert np.allclose(og["epot_list"][:2], oo["epot_list"][:2], rtol=1e-10 if prec == 64 else 1e-4)
+    assert oo["epot_list"][1] > 0
+    g.run(25); o.run(25)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-8 if prec == 64 else 1e-4)

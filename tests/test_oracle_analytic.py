@@ -190,3 +190,36 @@ def test_tabulated_bond_reproduces_the_function_it_samples(make_oracle):
     hb = b.list_create(2, "TABULATED"); b.list_set_params(hb, [b.table_create(r[0], dr, e, f)]); b.list_add(hb, [[1, 2]])
     b.run(0)
     assert b.get_state("FORCE")[0, 0] == pytest.approx(-f[-1], rel=1e-12)
+
+
+def test_tabulated_angle_reproduces_the_function_it_samples(make_oracle, tmp_path):
+    """TabulatedAngular(itype=1) (angle func 8, gromacs_topology.py:1074-1080): a table of U = K (theta - theta0)^2,
+    -dU/dtheta in radians gives the harmonic angle's forces; and the .xvg (degrees) -> .pot (radians) conversion
+    of tools/convert_gromacs2espp.py:73-83 (x -> radians, f -> f*180/pi, rows 0 < theta <= pi)."""
+    import numpy as np
+    from chemlab_amd import workloads as W
+    from chemlab_amd.chemlab import tables
+    K, th0 = 40.0, np.deg2rad(110.0)
+    deg = np.arange(0, 181)                                          # GROMACS angle table: one row per degree, 0..180
+    xvg = tmp_path / "table_a3.xvg"
+    with open(xvg, "w") as fh:
+        for d in deg:
+            th = np.deg2rad(d)
+            fh.write("%g %.12g %.12g\n" % (d, K * (th - th0) ** 2, -2.0 * K * (th - th0) * np.pi / 180.0))   # f per degree
+    pot = tmp_path / "table_a3.pot"
+    assert tables.convert_table(str(xvg), str(pot)) == 180           # theta = 0 dropped
+    tab = np.loadtxt(pot)
+    assert tab[0, 0] == pytest.approx(np.deg2rad(1.0)) and tab[-1, 0] == pytest.approx(np.pi)
+    assert np.allclose(tab[:, 2], -2.0 * K * (tab[:, 0] - th0), rtol=1e-6, atol=1e-5)   # %15.8g: 8 significant digits
+    pos = np.array([[5.0, 5.0, 5.0], [6.0, 5.0, 5.0], [6.0 + np.cos(np.deg2rad(97.3)) * -1.0, 5.0 + np.sin(np.deg2rad(97.3)), 5.0]])
+    base = dict(n=3, box=[20.0, 20.0, 20.0], rc=2.5, skin=0.3, dt=0.001, ids=np.array([1, 2, 3]), types=np.zeros(3, np.int32), pos=pos,
+                vel=np.zeros((3, 3)), mass=np.ones(3), kT=1.0, gamma=0.0, seed=1, exclusions=np.array([[1, 2], [2, 3], [1, 3]]))
+    a, b = make_oracle(), make_oracle()
+    W.apply(base, a, thermostat=False); W.apply(base, b, thermostat=False)
+    ha = a.list_create(3, "ANG_HARMONIC"); a.list_set_params(ha, [K, th0]); a.list_add(ha, [[1, 2, 3]])
+    hb = b.list_create(3, "ANG_TABULATED"); b.list_set_params(hb, [b.table_create(tab[0, 0], tab[1, 0] - tab[0, 0], tab[:, 1], tab[:, 2])]); b.list_add(hb, [[1, 2, 3]])
+    a.run(0); b.run(0)
+    fa, fb = a.get_state("FORCE"), b.get_state("FORCE")
+    assert np.abs(fa).max() > 1.0
+    assert np.abs(fa - fb).max() < 2e-3 * np.abs(fa).max()          # linear interpolation on a one-degree grid
+    assert np.abs(fb.sum(0)).max() < 1e-12
