@@ -1489,7 +1489,7 @@ int chem_list_create(chem_ctx* ctx, int arity, int kind, int by_types) {
   REQUIRE(arity >= 2 && arity <= 4, CHEM_EINVAL, "list arity must be 2, 3 or 4");
   const bool ok = (arity == 2 && (kind == CHEM_POT_HARMONIC || kind == CHEM_POT_FENE || kind == CHEM_POT_TABULATED)) ||
                   (arity == 3 && (kind == CHEM_POT_ANG_HARMONIC || kind == CHEM_POT_ANG_COSINE || kind == CHEM_POT_ANG_TABULATED)) ||
-                  (arity == 4 && (kind == CHEM_POT_DIH_NCOS || kind == CHEM_POT_DIH_RB));
+                  (arity == 4 && (kind == CHEM_POT_DIH_NCOS || kind == CHEM_POT_DIH_RB || kind == CHEM_POT_DIH_TABULATED));
   REQUIRE(ok, CHEM_ENOTIMPL, "potential kind not supported for this arity");
   REQUIRE((int)CTX.top.lists.size() < CHEM_MAX_LISTS, CHEM_ENOSPC, "too many lists");
   HostList l; l.arity = arity; l.kind = kind; l.by_types = by_types ? 1 : 0;
@@ -1532,8 +1532,8 @@ int chem_list_set_params(chem_ctx* ctx, int list, int t1, int t2, int t3, int t4
   API_BEGIN
   HostTopology& t = CTX.top;
   REQUIRE(list >= 0 && list < (int)t.lists.size() && p && np >= 1 && np <= CHEM_MAX_POT_PARAMS, CHEM_EINVAL, "list_set_params");
-  if (t.lists[list].kind == CHEM_POT_TABULATED || t.lists[list].kind == CHEM_POT_ANG_TABULATED)
-    REQUIRE(p[0] >= 0 && p[0] < (double)t.btables.size() && p[0] == (double)(int)p[0], CHEM_EINVAL, "tabulated bonds/angles: parameter must be a handle from chem_table_create");
+  if (t.lists[list].kind == CHEM_POT_TABULATED || t.lists[list].kind == CHEM_POT_ANG_TABULATED || t.lists[list].kind == CHEM_POT_DIH_TABULATED)
+    REQUIRE(p[0] >= 0 && p[0] < (double)t.btables.size() && p[0] == (double)(int)p[0], CHEM_EINVAL, "tabulated bonded terms: parameter must be a handle from chem_table_create");
   HostList& l = t.lists[list];
   std::array<double, CHEM_MAX_POT_PARAMS> v{};
   std::copy(p, p + np, v.begin());

@@ -1496,6 +1496,17 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
         for (int k = 0; k < 6; ++k) { u += p[k] * pw; if (k < 5) dsum += (k + 1) * p[k + 1] * pw; pw *= cp; }
         dU = -sp * dsum;
       }
+      else if (bp.kind == CHEM_POT_DIH_TABULATED) {   // TabulatedDihedral(itype=1): U(phi), -dU/dphi on a uniform grid over [-pi, pi]
+        const double4 ti = bt.info[(int)p[0]];
+        const double2* row = bt.rows + (size_t)ti.x;
+        const int nrow = (int)ti.y;
+        const double t = (phi - ti.z) * ti.w;
+        double fv;
+        if (t <= 0) { u = row[0].x; fv = row[0].y; }
+        else if (t >= (double)(nrow - 1)) { u = row[nrow - 1].x; fv = row[nrow - 1].y; }
+        else { const int k = (int)t; const double w = t - (double)k; const double2 a = row[k], b = row[k + 1]; u = a.x + w * (b.x - a.x); fv = a.y + w * (b.y - a.y); }
+        dU = -fv;
+      }
       const D3 g1 = (-lb / m2) * m, g4 = (lb / n2) * nn;
       const double s12 = dot3(b1, b2) / lb2, s32 = dot3(b3, b2) / lb2;
       D3 g;

@@ -328,6 +328,10 @@ class _TabulatedAngular(_Tabulated):
     """interaction.TabulatedAngular(itype, filename): rows `theta U -dU/dtheta` (radians) of a table_a<N>.pot file."""
 
 
+class _TabulatedDihedral(_Tabulated):
+    """interaction.TabulatedDihedral(itype, filename): rows `phi U -dU/dphi` (radians, [-pi, pi]) of a table_d<N>.pot file."""
+
+
 class _Harmonic(_Pot):
     kind = "HARMONIC"
 
@@ -424,7 +428,7 @@ class _FixedListInteraction(object):
         """(kind, parameter list) of a potential object; a Tabulated bond potential (func 8,
         gromacs_topology.py:919-925) registers its rows once per engine and passes the table handle."""
         if isinstance(pot, _Tabulated):
-            kind = "ANG_TABULATED" if isinstance(pot, _TabulatedAngular) else "TABULATED"
+            kind = "ANG_TABULATED" if isinstance(pot, _TabulatedAngular) else ("DIH_TABULATED" if isinstance(pot, _TabulatedDihedral) else "TABULATED")
             eng = self.system.engine
             cache = pot.__dict__.setdefault("_handles", {})
             if id(eng) not in cache:
@@ -486,7 +490,8 @@ interaction = _ns(
     # out of scope
     FENELennardJones=_unsupported("interaction.FENELennardJones"), CoulombTruncated=_unsupported("interaction.CoulombTruncated"),
     VerletListCoulombTruncated=_unsupported("interaction.VerletListCoulombTruncated"),
-    TabulatedAngular=_TabulatedAngular, TabulatedDihedral=_unsupported("interaction.TabulatedDihedral"),
+    TabulatedAngular=_TabulatedAngular, TabulatedDihedral=_TabulatedDihedral,
+    FixedQuadrupleListTabulatedDihedral=_FixedListInteraction, FixedQuadrupleListTypesTabulatedDihedral=_FixedListTypesInteraction,
     FixedPairListTabulated=_FixedListInteraction, FixedPairListTypesTabulated=_FixedListTypesInteraction,
     FixedTripleListTabulatedAngular=_FixedListInteraction, FixedTripleListTypesTabulatedAngular=_FixedListTypesInteraction,
     FixedPairListLambdaHarmonic=_unsupported("interaction.FixedPairListLambdaHarmonic"),

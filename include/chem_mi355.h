@@ -59,6 +59,7 @@ extern "C" {
 #define CHEM_POT_ANG_TABULATED 12  /* angles func 8: params = { table handle }, grid in radians, f = -dU/dtheta */
 #define CHEM_POT_DIH_NCOS     20
 #define CHEM_POT_DIH_RB       21
+#define CHEM_POT_DIH_TABULATED 22  /* dihedrals func 8: params = { table handle }, grid in radians over [-pi, pi], f = -dU/dphi */
 #define CHEM_MAX_POT_PARAMS    6
 #define CHEM_MAX_LISTS        32
 #define CHEM_MAX_TYPES        16
@@ -184,7 +185,8 @@ int chem_list_create(chem_ctx* ctx, int arity, int potential_kind, int by_types)
  * interpolation of e(r) and f(r), F_ij = f(r)/r * r_ij, first/last row beyond the grid.  Returns a table
  * handle >= 0 that is passed as the single parameter of a CHEM_POT_TABULATED list (plain or per type pair).
  * The same registry serves interaction.TabulatedAngular (angles func 8, table_a<N>.pot, gromacs_topology.py:1074-1080):
- * grid in radians, columns U(theta) and -dU/dtheta, list kind CHEM_POT_ANG_TABULATED. */
+ * grid in radians, columns U(theta) and -dU/dtheta, list kind CHEM_POT_ANG_TABULATED; and interaction.TabulatedDihedral
+ * (dihedrals func 8, table_d<N>.pot, gromacs_topology.py:1192-1198): grid over [-pi, pi], kind CHEM_POT_DIH_TABULATED. */
 int chem_table_create(chem_ctx* ctx, int64_t nrow, double r0, double dr, const double* e, const double* f);
 /* addBonds/addTriples/addQuadruples: ids is n*arity particle ids */
 int chem_list_add(chem_ctx* ctx, int list, int64_t n, const int64_t* ids);

@@ -295,6 +295,15 @@ static void bonded_forces(Orc& o) {
           double psi = phi - M_PI, cp = std::cos(psi), sp = std::sin(psi), pw = 1.0, dsum = 0;
           for (int k = 0; k < 6; ++k) { u += p[k] * pw; if (k < 5) { dsum += (k + 1) * p[k + 1] * pw; } pw *= cp; }
           dU = -sp * dsum;
+        } else if (l.kind == CHEM_POT_DIH_TABULATED) {   // TabulatedDihedral(itype=1): U(phi), -dU/dphi, gromacs_topology.py:1192-1198
+          const Orc::BTable& tb = o.btables[(size_t)p[0]];
+          const int64_t nrow = (int64_t)tb.e.size();
+          const double tt = (phi - tb.r0) / tb.dr;
+          double fv;
+          if (tt <= 0) { u = tb.e[0]; fv = tb.f[0]; }
+          else if (tt >= (double)(nrow - 1)) { u = tb.e[nrow - 1]; fv = tb.f[nrow - 1]; }
+          else { const int64_t k = (int64_t)tt; const double w = tt - (double)k; u = tb.e[k] + w * (tb.e[k + 1] - tb.e[k]); fv = tb.f[k] + w * (tb.f[k + 1] - tb.f[k]); }
+          dU = -fv;
         }
         // dphi/dx (Blondel & Karplus)
         Vec3 g1 = (-lb / m2) * m, g4 = (lb / n2) * nn;

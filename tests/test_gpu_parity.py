@@ -132,6 +132,12 @@ def test_dihedral_and_fene_and_cosine(make_gpu, make_oracle):
                        dict(arity=4, kind="DIH_RB", params=[0.5, -0.3, 0.2, 0.1, -0.1, 0.05], ids=ids[::2])],
                 exclusions=np.concatenate([ids[:, [0, 1]], ids[:, [1, 2]], ids[:, [2, 3]], ids[:, [0, 2]], ids[:, [1, 3]], ids[:, [0, 3]]]))
     g, o, _ = both(make_gpu, make_oracle, spec, 64)
+    dphi = 2 * np.pi / 720                                    # a tabulated dihedral (func 8) on every third molecule as well
+    phi = -np.pi + dphi * np.arange(721)
+    for eng in (g, o):
+        h = eng.list_create(4, "DIH_TABULATED")
+        eng.list_set_params(h, [eng.table_create(phi[0], dphi, 0.8 * (1 + np.cos(2 * phi - 0.3)), 1.6 * np.sin(2 * phi - 0.3))])
+        eng.list_add(h, ids[::3])
     g.run(0); o.run(0)
     assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-10
     og, oo = g.observe(), o.observe()

@@ -223,3 +223,27 @@ def test_tabulated_angle_reproduces_the_function_it_samples(make_oracle, tmp_pat
     assert np.abs(fa).max() > 1.0
     assert np.abs(fa - fb).max() < 2e-3 * np.abs(fa).max()          # linear interpolation on a one-degree grid
     assert np.abs(fb.sum(0)).max() < 1e-12
+
+
+def test_tabulated_dihedral_reproduces_the_function_it_samples(make_oracle):
+    """TabulatedDihedral(itype=1) (dihedral func 8, gromacs_topology.py:1192-1198): a table of U = K (1 + cos(n phi - phi0))
+    and -dU/dphi over [-pi, pi] gives the DihedralHarmonicNCos forces up to the interpolation error."""
+    import numpy as np
+    from chemlab_amd import workloads as W
+    K, phi0, mult = 1.5, np.deg2rad(20.0), 3.0
+    dphi = 2 * np.pi / 1440
+    phi = -np.pi + dphi * np.arange(1441)
+    e, f = K * (1.0 + np.cos(mult * phi - phi0)), K * mult * np.sin(mult * phi - phi0)
+    pos = np.array([[5.0, 5.0, 5.0], [5.9, 5.2, 5.1], [6.2, 6.1, 5.4], [7.1, 6.3, 6.2]])
+    base = dict(n=4, box=[20.0, 20.0, 20.0], rc=2.5, skin=0.3, dt=0.001, ids=np.arange(1, 5), types=np.zeros(4, np.int32), pos=pos,
+                vel=np.zeros((4, 3)), mass=np.ones(4), kT=1.0, gamma=0.0, seed=1,
+                exclusions=np.array([[1, 2], [2, 3], [3, 4], [1, 3], [2, 4], [1, 4]]))
+    a, b = make_oracle(), make_oracle()
+    W.apply(base, a, thermostat=False); W.apply(base, b, thermostat=False)
+    ha = a.list_create(4, "DIH_NCOS"); a.list_set_params(ha, [K, phi0, mult]); a.list_add(ha, [[1, 2, 3, 4]])
+    hb = b.list_create(4, "DIH_TABULATED"); b.list_set_params(hb, [b.table_create(phi[0], dphi, e, f)]); b.list_add(hb, [[1, 2, 3, 4]])
+    a.run(0); b.run(0)
+    fa, fb = a.get_state("FORCE"), b.get_state("FORCE")
+    assert np.abs(fa).max() > 0.1
+    assert np.abs(fa - fb).max() < 1e-4 * np.abs(fa).max()
+    assert b.observe()["epot_list"][0] == pytest.approx(a.observe()["epot_list"][0], rel=1e-4)
