@@ -81,6 +81,7 @@ struct Ctx {
   std::string err;
   int device = 0, prec = 32;
   double L[3] = {0, 0, 0}, rc = 0, skin = 0, dt = 0, cap_force = 0;
+  int resc_kind = 0; double resc_kT = 0, resc_param = 0;   // Berendsen (1) / Isokinetic (2) velocity rescaling
   HostTopology top;
   std::vector<double> pos0, vel0;  // staged particle data (tag order) until first upload
   int ntypes = 1;
@@ -880,6 +881,22 @@ template <typename R> struct CtxT : Ctx {
     if (hf[0]) { rebuild_dd(); compute_forces(); }
   }
 
+  // Berendsen / Isokinetic: scale factor from the global kinetic energy, then one streaming pass over v
+  DBuf<double> resc_buf;   // [0] Ekin (local, then global), [1] lambda
+  void rescale_velocities() {
+    const int nkb = cdiv(n, 256);
+    resc_buf.alloc(2);
+    hipLaunchKernelGGL(k_kinetic<R>, dim3(nkb), dim3(256), 0, stream, G, n, v4.p, ekout.p);
+    const bool multi = dd_on && P > 1;
+    hipLaunchKernelGGL(k_rescale_lambda, dim3(1), dim3(256), 0, stream, ekout.p, nkb, resc_buf.p, multi ? (double*)nullptr : resc_buf.p + 1,
+                       resc_kind, resc_kT, dt / resc_param, (double)nglob);
+    if (multi) {
+      tr->allreduce_sum_f64(resc_buf.p, 1, stream);
+      hipLaunchKernelGGL(k_rescale_lambda, dim3(1), dim3(256), 0, stream, ekout.p, 0, resc_buf.p, resc_buf.p + 1, resc_kind, resc_kT, dt / resc_param, (double)nglob);
+    }
+    hipLaunchKernelGGL(k_scale_v<R>, dim3(nkb), dim3(256), 0, stream, G, n, v4.p, resc_buf.p + 1);
+  }
+
   // ---- the hot call -------------------------------------------------------------------
   void run(int64_t nsteps) override {
     if (!(dt > 0)) throw ChemError(CHEM_ESTATE, "dt not set");
@@ -920,9 +937,10 @@ template <typename R> struct CtxT : Ctx {
 
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
       const bool last = (s == nsteps - 1);
-      if (last || react_due || !opt_fuse) {
+      if (last || react_due || !opt_fuse || resc_kind) {
         launch_integrate<1>(lang, lang, step, 1);
         ++step;
+        if (resc_kind == 1 || (resc_kind == 2 && step % (int64_t)resc_param == 0)) rescale_velocities();
         if (react_due) react_step();
         need_int1 = true;
       } else {
@@ -1564,6 +1582,17 @@ int64_t chem_get_list(chem_ctx* ctx, int list, int64_t* out, int64_t cap) {
 int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t seed) {
   API_BEGIN
   CTX.lang = gamma > 0 && kT >= 0; CTX.kT = kT; CTX.gamma = gamma; CTX.lang_seed = seed;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_thermostat_rescale(chem_ctx* ctx, int kind, double kT, double param) {
+  API_BEGIN
+  REQUIRE(kind >= 0 && kind <= 2, CHEM_EINVAL, "thermostat_rescale: kind must be 0 (off), 1 (Berendsen) or 2 (Isokinetic)");
+  if (kind) REQUIRE(kT > 0, CHEM_EINVAL, "thermostat_rescale: temperature");
+  if (kind == 1) REQUIRE(param > 0, CHEM_EINVAL, "Berendsen: tau must be > 0");
+  if (kind == 2) REQUIRE(param >= 1, CHEM_EINVAL, "Isokinetic: coupling must be >= 1 step");
+  CTX.resc_kind = kind; CTX.resc_kT = kT; CTX.resc_param = kind == 2 ? std::floor(param) : param;
   return 0;
   API_END(ctx)
 }

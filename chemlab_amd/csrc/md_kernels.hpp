@@ -1873,6 +1873,37 @@ __global__ __launch_bounds__(256) void k_kinetic(int i0, int n, const Vec4<R>* _
   }
 }
 
+// ---- velocity-rescaling thermostats (Berendsen, Isokinetic; start_simulation.py:341-348) --------
+// k_kinetic leaves per-block (Ekin, p) partials; one block folds them into the scale factor, a
+// streaming kernel applies it.  Decomposed path: the fold writes the local Ekin, the ranks sum it
+// (transport all-reduce), k_rescale_lambda is launched with nblk = 0 and reads the sum.
+__global__ __launch_bounds__(256) void k_rescale_lambda(const double* __restrict__ part, int nblk, double* __restrict__ ekin_io, double* __restrict__ lam_out,
+                                                        int kind, double kT, double pref /* dt/tau */, double ntot) {
+  __shared__ double red[4];
+  double ek = 0;
+  for (int k = threadIdx.x; k < nblk; k += blockDim.x) ek += part[4 * k];
+  for (int o = 32; o > 0; o >>= 1) ek += __shfl_xor(ek, o);
+  if (lane_id() == 0) red[threadIdx.x >> 6] = ek;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (nblk > 0) { ek = red[0] + red[1] + red[2] + red[3]; *ekin_io = ek; }
+    else ek = *ekin_io;
+    if (lam_out) {
+      const double kTnow = 2.0 * ek / (3.0 * ntot);
+      *lam_out = kind == 1 ? sqrt(1.0 + pref * (kT / kTnow - 1.0)) : sqrt(kT / kTnow);
+    }
+  }
+}
+template <typename R>
+__global__ __launch_bounds__(256) void k_scale_v(int i0, int n, Vec4<R>* __restrict__ v4, const double* __restrict__ lam) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= i0 + n) return;
+  const R s = (R)*lam;
+  Vec4<R> v = v4[i];
+  v.x *= s; v.y *= s; v.z *= s;
+  v4[i] = v;
+}
+
 // =======================================================================================
 // K9/K10  reaction scan + resolve (integrator.ChemicalReaction / Reaction,
 //     reaction_setup.py:71-165,416-427)

@@ -135,6 +135,11 @@ class Engine:
         assert e.shape == f.shape
         return self._ck(self.api.table_create(self.ctx, e.shape[0], float(r0), float(dr), _ptr(e, C.c_double), _ptr(f, C.c_double)))
 
+    def thermostat_rescale(self, kind, kT, param):
+        """kind: 'berendsen' (param = tau), 'isokinetic' (param = coupling steps) or None/0 (off)."""
+        k = {None: 0, 0: 0, "berendsen": 1, 1: 1, "isokinetic": 2, 2: 2}[kind]
+        self._ck(self.api.thermostat_rescale(self.ctx, k, float(kT), float(param)))
+
     def cap_force(self, max_force):
         self._ck(self.api.cap_force(self.ctx, float(max_force)))
 

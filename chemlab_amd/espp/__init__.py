@@ -576,6 +576,32 @@ class _LangevinThermostat(object):
         self.system.engine.thermostat_langevin(self.temperature, self.gamma, seed)
 
 
+class _BerendsenThermostat(object):
+    """integrator.BerendsenThermostat(system): .temperature (= T*kb), .tau (start_simulation.py:341-344)."""
+
+    def __init__(self, system):
+        self.system, self.temperature, self.tau = system, 0.0, 1.0
+
+    def _connect(self, integrator):
+        self.system.engine.thermostat_rescale("berendsen", self.temperature, self.tau)
+
+    def disconnect(self):
+        self.system.engine.thermostat_rescale(None, 1.0, 1.0)
+
+
+class _Isokinetic(object):
+    """integrator.Isokinetic(system): .temperature, .coupling = rescale every `coupling` steps (start_simulation.py:345-348)."""
+
+    def __init__(self, system):
+        self.system, self.temperature, self.coupling = system, 0.0, 1
+
+    def _connect(self, integrator):
+        self.system.engine.thermostat_rescale("isokinetic", self.temperature, int(self.coupling))
+
+    def disconnect(self):
+        self.system.engine.thermostat_rescale(None, 1.0, 1.0)
+
+
 class _CapForce(object):
     """integrator.CapForce(system, max_force) (start_simulation.py:320-324): conservative force of a particle
     rescaled to |f| = max_force where it exceeds it, before the thermostat's terms."""
@@ -769,8 +795,8 @@ integrator = _ns(
     Reaction=_Reaction, PostProcessChangeProperty=_PostProcessChangeProperty,
     TopologyParticleProperties=_TopologyParticleProperties, TopologyManager=_TopologyManager, ExtAnalyze=_ExtAnalyze,
     StochasticVelocityRescaling=_unsupported("integrator.StochasticVelocityRescaling"),
-    BerendsenThermostat=_unsupported("integrator.BerendsenThermostat"), BerendsenBarostat=_unsupported("integrator.BerendsenBarostat"),
-    Isokinetic=_unsupported("integrator.Isokinetic"), LangevinBarostat=_unsupported("integrator.LangevinBarostat"),
+    BerendsenThermostat=_BerendsenThermostat, BerendsenBarostat=_unsupported("integrator.BerendsenBarostat"),
+    Isokinetic=_Isokinetic, LangevinBarostat=_unsupported("integrator.LangevinBarostat"),
     CapForce=_CapForce, RestrictReaction=_unsupported("integrator.RestrictReaction"),
     DissociationReaction=_unsupported("integrator.DissociationReaction"), ATRPActivator=_unsupported("integrator.ATRPActivator"),
     ReactionCutoffRandom=_unsupported("integrator.ReactionCutoffRandom"), FixDistances=_unsupported("integrator.FixDistances"),

@@ -200,6 +200,13 @@ int64_t chem_get_list(chem_ctx* ctx, int list, int64_t* out, int64_t cap_entries
 /* integrator.LangevinThermostat: .temperature (=T*kb), .gamma  start_simulation.py:330-336.
  * gamma<=0 or kT<0 switches it off (thermostat=no, Q6 in SURVEY). */
 int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t seed);
+/* integrator.BerendsenThermostat(system) (.temperature, .tau) and integrator.Isokinetic(system) (.temperature,
+ * .coupling) -- start_simulation.py:341-348 (`thermostat = br | iso`): velocity rescaling after the second half
+ * kick of a step (aftIntV).  With kT_now = 2 Ekin / (3 N):
+ *   kind 1 Berendsen : v *= sqrt(1 + dt/tau * (kT/kT_now - 1)) every step            (param = tau)
+ *   kind 2 Isokinetic: v *= sqrt(kT/kT_now) every `param` steps                       (param = coupling, >= 1)
+ *   kind 0 switches it off.  Independent of chem_thermostat_langevin (the driver uses one of them). */
+int chem_thermostat_rescale(chem_ctx* ctx, int kind, double kT, double param);
 /* integrator.CapForce(system, max_force), added before the thermostat -- start_simulation.py:320-324
  * (`max_force`, app_args default -1 = off): after every force evaluation the conservative force of a
  * particle is rescaled to |f| = max_force where it exceeds it; the thermostat's friction and noise come

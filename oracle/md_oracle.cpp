@@ -104,6 +104,7 @@ struct Orc {
   std::vector<std::pair<int32_t, int32_t>> pairs;  // half Verlet list
   int64_t rebuilds = 0, reaction_steps = 0;
   double cap_force = 0;
+  int resc_kind = 0; double resc_kT = 0, resc_param = 0;   // Berendsen / Isokinetic (chem_thermostat_rescale)
   struct BTable { double r0, dr; std::vector<double> e, f; };
   std::vector<BTable> btables;   // chem_table_create registry (tabulated bonds)
   double e_lj = 0, e_tab = 0, virial = 0;
@@ -516,6 +517,13 @@ static void run(Orc& o, int64_t nsteps) {
     update_forces(o, o.step, 1);
     for (int64_t i = 0; i < o.n; ++i) o.v[i] = o.v[i] + (0.5 * o.dt / o.mass[i]) * o.f[i];
     o.step++;
+    if (o.resc_kind == 1 || (o.resc_kind == 2 && o.step % (int64_t)o.resc_param == 0)) {   // aftIntV, start_simulation.py:341-348
+      double ek = 0;
+      for (int64_t i = 0; i < o.n; ++i) ek += 0.5 * o.mass[i] * dot(o.v[i], o.v[i]);
+      const double kTnow = 2.0 * ek / (3.0 * (double)o.n);
+      const double lam = o.resc_kind == 1 ? std::sqrt(1.0 + o.dt / o.resc_param * (o.resc_kT / kTnow - 1.0)) : std::sqrt(o.resc_kT / kTnow);
+      for (int64_t i = 0; i < o.n; ++i) o.v[i] = lam * o.v[i];
+    }
     if (o.react_on && o.interval > 0 && o.step % o.interval == 0) react(o);
   }
 }
@@ -652,6 +660,11 @@ int orc_table_create(void* c, int64_t nrow, double r0, double dr, const double* 
   Orc::BTable t; t.r0 = r0; t.dr = dr; t.e.assign(e, e + nrow); t.f.assign(f, f + nrow);
   o.btables.push_back(std::move(t));
   return (int)o.btables.size() - 1;
+}
+int orc_thermostat_rescale(void* c, int kind, double kT, double param) {
+  Orc& o = O(c);
+  if (kind < 0 || kind > 2 || (kind && !(kT > 0)) || (kind == 1 && !(param > 0)) || (kind == 2 && param < 1)) FAIL(CHEM_EINVAL, "thermostat_rescale");
+  o.resc_kind = kind; o.resc_kT = kT; o.resc_param = kind == 2 ? std::floor(param) : param; return 0;
 }
 int orc_cap_force(void* c, double max_force) { O(c).cap_force = max_force > 0 ? max_force : 0; return 0; }
 int orc_thermostat_langevin(void* c, double kT, double gamma, uint64_t seed) {

@@ -820,3 +820,24 @@ def test_tabulated_angles_match_oracle(make_gpu, make_oracle, prec):
     assert oo["epot_list"][1] > 0
     g.run(25); o.run(25)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-8 if prec == 64 else 1e-4)
+
+
+@pytest.mark.parametrize("kind,param,transport", [("berendsen", 0.05, None), ("isokinetic", 4, None), ("berendsen", 0.05, "dd_self")])
+def test_rescaling_thermostats_match_oracle(make_gpu, make_oracle, kind, param, transport):
+    """SURVEY f-1: BerendsenThermostat / Isokinetic -- global kinetic energy reduction + scaling pass every (k-th) step."""
+    spec = W.lj_melt(n=8788, seed=31, jitter=0.08, kT=1.5)
+    spec["rebuild_criterion"] = 0
+    g, o = make_gpu(64), make_oracle()
+    if transport:
+        g.set_option(transport, 1)
+    W.apply(spec, g, thermostat=False); W.apply(spec, o, thermostat=False)
+    for e in (g, o):
+        e.thermostat_rescale(kind, 0.9, param)
+    g.run(60); o.run(60)
+    assert g.observe()["temperature"] == pytest.approx(o.observe()["temperature"], rel=1e-9)
+    assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < 1e-8
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+    for e in (g, o):
+        e.thermostat_rescale(None, 1.0, 1.0)
+    g.run(10); o.run(10)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9

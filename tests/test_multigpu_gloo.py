@@ -30,7 +30,9 @@ assert int(t[0]) == spec["n"], (int(t[0]), spec["n"])          # every particle 
 mx = multigpu.max_over_ranks(dist, 1.0 + rank)
 assert mx == float(world)
 dist.barrier()
-print(json.dumps(dict(rank=rank, mine=mine)))
+# one file per rank: the two workers share a stdout pipe and their lines can interleave
+with open(os.path.join(%r, 'rank_%%d.json' %% rank), 'w') as fh:
+    json.dump(dict(rank=rank, mine=mine), fh)
 '''
 
 
@@ -51,7 +53,7 @@ def test_owner_of_matches_layers():
 
 def test_two_rank_gloo_rendezvous_and_partition(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
+    script.write_text(WORKER % (ROOT, str(tmp_path)))
     import socket
     with socket.socket() as sk:          # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
@@ -61,5 +63,6 @@ def test_two_rank_gloo_rendezvous_and_partition(tmp_path):
            "--master-port", str(port), str(script)]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 2
+    import json
+    out = [json.load(open(tmp_path / ("rank_%d.json" % r))) for r in range(2)]
+    assert [o["rank"] for o in out] == [0, 1]

@@ -247,3 +247,28 @@ def test_tabulated_dihedral_reproduces_the_function_it_samples(make_oracle):
     assert np.abs(fa).max() > 0.1
     assert np.abs(fa - fb).max() < 1e-4 * np.abs(fa).max()
     assert b.observe()["epot_list"][0] == pytest.approx(a.observe()["epot_list"][0], rel=1e-4)
+
+
+def test_berendsen_and_isokinetic_rescaling(make_oracle):
+    """integrator.BerendsenThermostat / Isokinetic (start_simulation.py:341-348): after a step the kinetic temperature
+    kT = 2 Ekin / (3 N) is pulled towards the target by v *= sqrt(1 + dt/tau (kT0/kT - 1)), resp. set to it exactly."""
+    import numpy as np
+    from chemlab_amd import workloads as W
+    spec = W.lj_melt(n=500, seed=4, kT=1.0)
+    kT0 = 0.6
+    o = make_oracle(); W.apply(spec, o, thermostat=False)
+    o.thermostat_rescale("isokinetic", kT0, 5)
+    o.run(5)
+    assert o.observe()["temperature"] == pytest.approx(kT0, rel=1e-12)       # exactly on target right after a coupling step
+    o.run(3)
+    assert abs(o.observe()["temperature"] - kT0) > 1e-6                      # free flight in between
+    a, b = make_oracle(), make_oracle()
+    W.apply(spec, a, thermostat=False); W.apply(spec, b, thermostat=False)
+    tau = 0.05
+    b.thermostat_rescale("berendsen", kT0, tau)
+    a.run(1); b.run(1)
+    kTa, va, vb = a.observe()["temperature"], a.get_state("VEL"), b.get_state("VEL")
+    lam = np.sqrt(1.0 + spec["dt"] / tau * (kT0 / kTa - 1.0))
+    assert np.allclose(vb, lam * va, rtol=1e-12, atol=1e-14)                 # one step: same trajectory, scaled at the end
+    b.run(400)
+    assert b.observe()["temperature"] == pytest.approx(kT0, rel=0.05)        # relaxed to the target
