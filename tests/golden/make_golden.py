@@ -7,6 +7,7 @@ What is produced and why:
                              under py3) on each example's `params` file           -> pins chemlab/app_args.py
   table_nb_excerpt.{xvg,pot} first rows of a GROMACS non-bonded table and the reference converter's output
   table_b1_excerpt.{xvg,pot} same for a bonded table (src/tests/table_b1.xvg)    -> pins chemlab/tables.py
+  table_a5_excerpt.{xvg,pot} same for an angle table (examples/atrp_activator/table_a5.xvg): degrees -> radians
   setup_known_answers.json   counts / cell grid / type order printed in examples/atrp_lj/single
   data files (inputs, not source): src/tests/{topol.top,*.itp}, examples/atrp_lj/*, examples/chain_growth_catalytic/*
 """
@@ -37,7 +38,9 @@ def main():
         body = [l for l in lines if l.strip() and l.strip()[0] not in "#@"][:nrows]
         open(dst, "w").writelines(head + body)
     for stem, src in [("table_nb_excerpt", os.path.join(REF, "examples/mf/espp_cg_1_water/table_A_A.xvg")),
-                      ("table_b1_excerpt", os.path.join(REF, "src/tests/table_b1.xvg"))]:
+                      ("table_b1_excerpt", os.path.join(REF, "src/tests/table_b1.xvg")),
+                      # angle table: the converter decides by the `_a<N>` in the file name (degrees -> radians, theta = 0 dropped)
+                      ("table_a5_excerpt", os.path.join(REF, "examples/atrp_activator/table_a5.xvg"))]:
         xvg = os.path.join(HERE, stem + ".xvg")
         excerpt(src, xvg, 50)
         conv.convertTable(xvg, os.path.join(HERE, stem + ".pot"), 1, 1, 1, 1)
