@@ -9,7 +9,8 @@ What is produced and why:
   table_b1_excerpt.{xvg,pot} same for a bonded table (src/tests/table_b1.xvg)    -> pins chemlab/tables.py
   table_a5_excerpt.{xvg,pot} same for an angle table (examples/atrp_activator/table_a5.xvg): degrees -> radians
   setup_known_answers.json   counts / cell grid / type order printed in examples/atrp_lj/single
-  data files (inputs, not source): src/tests/{topol.top,*.itp}, examples/atrp_lj/*, examples/chain_growth_catalytic/*
+  data files (inputs, not source): src/tests/{topol.top,*.itp}, examples/atrp_lj/*, examples/chain_growth_catalytic/*,
+                             examples/mf/espp_cg_1/{conf.gro,topol.top,params,reaction.cfg,table_A_A.xvg}
 """
 import json
 import os
@@ -47,7 +48,9 @@ def main():
 
     copies = {"src_tests": ["src/tests/topol.top", "src/tests/diol_cg.itp", "src/tests/ter_cg.itp"],
               "atrp_lj": ["examples/atrp_lj/%s" % f for f in ("conf.gro", "topol.top", "ffnb.itp", "exclusion_topol.list", "params", "atrp.cfg")],
-              "chain_growth_catalytic": ["examples/chain_growth_catalytic/%s" % f for f in ("conf.gro", "topol.top", "params", "reaction.cfg")]}
+              "chain_growth_catalytic": ["examples/chain_growth_catalytic/%s" % f for f in ("conf.gro", "topol.top", "params", "reaction.cfg")],
+              # 1000-bead melt with a GROMACS non-bonded table (nonbond_params func 8, table_groups=A) and harmonic reaction bonds
+              "mf_espp_cg_1": ["examples/mf/espp_cg_1/%s" % f for f in ("conf.gro", "topol.top", "params", "reaction.cfg", "table_A_A.xvg")]}
     for sub, files in copies.items():
         os.makedirs(os.path.join(HERE, sub), exist_ok=True)
         for f in files:

@@ -465,13 +465,16 @@ def test_dd_multi_rank_in_process_reactive(make_gpu, make_oracle, chunks):
         assert np.allclose(out[r]["el"], o.observe()["epot_list"], rtol=1e-9)
 
 
-def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mod):
-    """The py3 start_simulation driver (readers -> espressopp-shaped shim -> C ABI) on the shipped
-    chain_growth_catalytic inputs: HIP engine (fp64) vs the oracle behind the same shim."""
+@pytest.mark.parametrize("example,argv,min_events", [
+    ("chain_growth_catalytic", ["@params", "--run=2500", "--start_ar=500"], 100),
+    ("mf_espp_cg_1", ["@params", "--run=3000", "--start_ar=1000", "--int_step=500", "--energy_collect=500", "--trj_collect=1000", "--rng_seed=7"], 5)])
+def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mod, example, argv, min_events):
+    """The py3 start_simulation driver (readers -> espressopp-shaped shim -> C ABI) on shipped example inputs
+    (LJ chain growth; tabulated non-bonded melt with Langevin at 800 K): HIP engine (fp64) vs the oracle behind the same shim."""
     import os, shutil
     from chemlab_amd import espp, start_simulation
     from chemlab_amd.engine import Engine
-    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chain_growth_catalytic")
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", example)
     out = {}
     for name, fac in (("gpu", lambda: Engine(device=0, precision=64)), ("oracle", lambda: oracle_mod.OracleEngine())):
         d = tmp_path / name
@@ -479,13 +482,13 @@ def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mo
         monkeypatch.chdir(d)
         espp.set_engine_factory(fac)
         try:
-            res = start_simulation.main(["@params", "--run=2500", "--start_ar=500"], quiet=True)
+            res = start_simulation.main(list(argv), quiet=True)
         finally:
             espp.set_engine_factory(lambda: Engine(device=0, precision=32))
         e = res["system"].engine
         out[name] = dict(ev=sorted_events(e.get_events()), bonds=res["chem_fpls"][0][1].getAllBonds(), st=e.get_state("STATE"),
                          ty=e.get_state("TYPE"), x=e.get_state("POS_UNFOLDED"))
-    assert len(out["oracle"]["ev"]) > 100
+    assert len(out["oracle"]["ev"]) > min_events
     assert [v[:4] for v in out["gpu"]["ev"]] == [v[:4] for v in out["oracle"]["ev"]]
     assert out["gpu"]["bonds"] == out["oracle"]["bonds"]
     assert np.array_equal(out["gpu"]["st"], out["oracle"]["st"]) and np.array_equal(out["gpu"]["ty"], out["oracle"]["ty"])
