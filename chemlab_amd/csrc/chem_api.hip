@@ -773,7 +773,7 @@ template <typename R> struct CtxT : Ctx {
     pair_guard = speculative ? 256 : 0;
     pair_subset = subset;
     const int tpp = pick_tpp();
-    const bool timed = opt_time_pair && !speculative && (pair_launch_no++ % opt_time_pair) == 0 && ev_used + 2 <= ev.size();
+    const bool timed = opt_time_pair && subset == 0 && (pair_launch_no++ % opt_time_pair) == 0 && ev_used + 2 <= ev.size();
     if (timed) HIPCHK(hipEventRecord(ev[ev_used], stream));
     launch_pair<false>(f4.p, tpp);
     if (timed) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; }
@@ -952,9 +952,15 @@ template <typename R> struct CtxT : Ctx {
     tm.run_wall_s += now_s() - t0;
     tm.steps += nsteps;
     if (opt_time_pair && ev_used) {
-      double ms = 0;
-      for (size_t k = 0; k + 1 < ev_used; k += 2) { float t = 0; HIPCHK(hipEventElapsedTime(&t, ev[k], ev[k + 1])); ms += t; }
-      tm.pair_kernel_ms = ms; tm.pair_kernel_launches = (int64_t)(ev_used / 2);
+      // Decomposed path: speculative launches that met a pending rebuild leave at once; they are not
+      // force evaluations, so samples far below the median are dropped from the average.
+      std::vector<float> d;
+      for (size_t k = 0; k + 1 < ev_used; k += 2) { float t = 0; HIPCHK(hipEventElapsedTime(&t, ev[k], ev[k + 1])); d.push_back(t); }
+      std::vector<float> sorted_d(d); std::sort(sorted_d.begin(), sorted_d.end());
+      const float cut = dd_on ? 0.5f * sorted_d[sorted_d.size() / 2] : 0.f;
+      double ms = 0; int64_t cnt = 0;
+      for (float t : d) if (t >= cut) { ms += t; ++cnt; }
+      tm.pair_kernel_ms = ms; tm.pair_kernel_launches = cnt;
     }
   }
 

@@ -101,12 +101,16 @@ def bench_main(a, spec, rank, local_rank, world):
         eng.set_option(k, float(v))
     eng.run(a.warmup)
     device_sync(eng, local_rank)
+    if not getattr(a, "no_roofline", False):
+        eng.set_option("time_pair_kernel", 8)              # HIP events around every 8th force launch of the timed region
     dist.barrier()
     t0 = time.perf_counter()
     eng.run(a.steps)
     device_sync(eng, local_rank)
     dist.barrier()
     wall = max_over_ranks(dist, time.perf_counter() - t0)
+    tm = eng.timers()
+    eng.set_option("time_pair_kernel", 0)
     nev = len(eng.get_events())
     if rank == 0:
         sps = a.steps / wall
@@ -118,6 +122,15 @@ def bench_main(a, spec, rank, local_rank, world):
                                particles=a.n, reaction_interval=a.interval, reaction_events_total=nev,
                                tau_per_day=sps * spec["dt"] * 86400,
                                parallelism="spatial slab decomposition along z over %d GPUs, RCCL ghost-layer exchange" % world))
+        if tm["pair_kernel_launches"] > 0:
+            # per-GPU figure of rank 0: its slab's share of the force list against ONE GPU's HBM peak
+            avg_s = 1e-3 * tm["pair_kernel_ms"] / tm["pair_kernel_launches"]
+            n_loc = a.n / float(world)
+            nb = tm["nlist_entries"] / n_loc
+            bpp = 36.0 + 4.0 * nb
+            out["roofline"] = dict(bound="hbm", kernel="k_pair_tiles (rank 0, its slab)", achieved=n_loc * bpp / avg_s / 1e9, peak=8000.0, unit="GB/s",
+                                   frac=n_loc * bpp / avg_s / 8.0e12, traffic=None, avg_launch_us=avg_s * 1e6, launches=tm["pair_kernel_launches"],
+                                   mean_neighbours=nb, algorithmic_bytes_per_particle=bpp)
         print(json.dumps(out))
     dist.barrier()
     eng.close()
