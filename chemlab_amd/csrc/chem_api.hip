@@ -291,7 +291,7 @@ template <typename R> struct CtxT : Ctx {
   void launch_rebuild_fused() {
     FusedArgs<R> a{};
     a.n = n; a.ncell = box.ncell; a.ntiles = ntiles; a.CAP = tile_cap; a.S = S; a.has_excl = has_excl; a.criterion = opt_criterion;
-    a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = cdiv(n, 256); a.want32 = want32 ? 1 : 0;
+    a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = cdiv(n, kIntPerBlock); a.want32 = want32 ? 1 : 0;
     a.half_skin = 0.5 * skin; a.rl2 = (R)((rc + skin) * (rc + skin));
     a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
@@ -558,7 +558,7 @@ template <typename R> struct CtxT : Ctx {
 
   void decide_and_rebuild() {
     if (use_fused) { launch_rebuild_fused(); return; }
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, 256), 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, kIntPerBlock), 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
     launch_rebuild_chain();
   }
 
@@ -800,7 +800,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   template <int MODE> void launch_integrate(bool with_lang, bool storef, int64_t istep, int phase) {
-    const int nb = cdiv(n, 256);
+    const int nb = cdiv(n, kIntPerBlock);
     LangevinP<R> lp = lang_params(istep, phase);
     // CapForce acts on the freshly evaluated conservative force: every launch that applies the thermostat
     // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
@@ -840,7 +840,7 @@ template <typename R> struct CtxT : Ctx {
     // local fold -> ctl->step_m2; its all-to-all rides in the halo exchange group; decision from the
     // P gathered values, mirrored into pinned host memory so that the host learns it by polling one
     // word (no memcpy, no stream synchronisation call)
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), 256), 0.5 * skin, opt_criterion, 1,
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), kIntPerBlock), 0.5 * skin, opt_criterion, 1,
                        (const double*)nullptr, 0, (volatile int*)nullptr, 0);
     // Overlap: the halo exchange runs on the communication stream while the tiles that need no ghost
     // (every tile layer but the lowest and the highest of the slab) already compute their forces.

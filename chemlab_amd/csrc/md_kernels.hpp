@@ -35,6 +35,7 @@ __device__ __forceinline__ double rcp_r(double x) { return 1.0 / x; }
 __device__ __forceinline__ double floor_r(double x) { return floor(x); }
 
 constexpr int kMaxTypes = CHEM_MAX_TYPES;
+constexpr int kIntPerBlock = 512;   // particles per workgroup of k_integrate (= entries of the blockmax array per 512 particles)
 constexpr int kWave = 64;
 
 // ---- device-resident control block (one per context) ---------------------------------
@@ -122,28 +123,48 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
                                                     R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax,
                                                     const Vec4<R>* __restrict__ x0, R cap) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // kIntPerBlock particles per 256-thread block: every thread owns kIntPerBlock/256 particles and issues
+  // all their loads before the first dependent instruction (more bytes in flight per wave for this
+  // purely HBM-bound kernel); the arithmetic per particle is unchanged
+  constexpr int PPT = kIntPerBlock / 256;
+  const int base = blockIdx.x * kIntPerBlock + threadIdx.x;
+  Vec4<R> vv[PPT], ff[PPT], xx[PPT];
+  int tg[PPT];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int i = base + u * 256;
+    tg[u] = 0;
+    if (i < n) {
+      vv[u] = v4[i]; ff[u] = f4[i];
+      if (LANG) tg[u] = tag[i];
+      if (MODE & 2) xx[u] = x4[i];
+    }
+  }
   R d2 = 0;
-  if (i < n) {
-    Vec4<R> v = v4[i], f = f4[i];
+#pragma unroll
+  for (int u = 0; u < PPT; ++u) {
+    const int i = base + u * 256;
+    if (i >= n) continue;
+    Vec4<R> v = vv[u], f = ff[u];
     if (cap > (R)0) {   // CapForce: f4 holds the conservative force of this step (the host passes cap only then)
       const R f2 = f.x * f.x + f.y * f.y + f.z * f.z;
       if (f2 > cap * cap) { const R s = cap / sqrt_r(f2); f.x *= s; f.y *= s; f.z *= s; }
     }
     if (LANG) {
-      langevin_force<R>(lp, tag[i], v.w, v.x, v.y, v.z, f.x, f.y, f.z);
+      langevin_force<R>(lp, tg[u], v.w, v.x, v.y, v.z, f.x, f.y, f.z);
       if (STOREF) f4[i] = f;
     }
     R hm = (R)0.5 * dt / v.w;
     if (MODE & 1) { v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z; }
     if (MODE & 2) {
       v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z;
-      Vec4<R> x = x4[i];
+      Vec4<R> x = xx[u];
       R dx = dt * v.x, dy = dt * v.y, dz = dt * v.z;
       x.x += dx; x.y += dy; x.z += dz;
       x4[i] = x;
       if (x0) { const Vec4<R> o = x0[i]; dx = x.x - o.x; dy = x.y - o.y; dz = x.z - o.z; }
-      d2 = dx * dx + dy * dy + dz * dz;
+      const R dd = dx * dx + dy * dy + dz * dz;
+      d2 = dd > d2 ? dd : d2;
     }
     v4[i] = v;
   }
