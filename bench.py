@@ -8,6 +8,15 @@ A "step" is one velocity-Verlet MD step of the whole system (neighbour-list upke
 bonded forces, Langevin thermostat, and the reaction scan every `interval` steps), timed like the
 reference's integratorLoop (start_simulation.py:779-781): wall time inside run() only, inputs
 already resident in HBM.  Prints ONE JSON line (see DESIGN.md "Measurement").
+
+Sequence (all set-up outside the timer):
+  1. lattice start, `--equil` steps WITHOUT reactions: the melt the metric is named after
+     (the reference attaches the reaction extension at step `start_ar`, start_simulation.py:735-741);
+  2. reactions enabled, W warm-up steps, then EXACTLY K timed steps;
+  3. if no reaction step fell into the timed region (K < interval), the next reaction step is timed
+     on its own afterwards and reported as `reaction_step_ms` (it is never folded into `value`);
+  4. an fp64 run of the same melted state (`f64` object: the reference computes in fp64);
+  5. the CPU restatement on the same melted state, one core and all cores (`cpu_baseline`).
 """
 import argparse
 import json
@@ -31,8 +40,10 @@ def parse():
     p.add_argument("--n", type=int, default=1000000, help="particles (C5: 1,000,000 = 100^3 sc lattice)")
     p.add_argument("--rho", type=float, default=0.8)
     p.add_argument("--interval", type=int, default=500)
+    p.add_argument("--equil", type=int, default=2000, help="untimed melting steps before reactions are enabled")
     p.add_argument("--precision", type=int, default=32)
-    p.add_argument("--cpu-steps", type=int, default=8, help="oracle steps for the cpu_baseline leg (0 = skip)")
+    p.add_argument("--f64-steps", type=int, default=-1, help="timed steps of the fp64 leg (-1: min(K, 400); 0 = skip)")
+    p.add_argument("--cpu-steps", type=int, default=-1, help="oracle steps per cpu_baseline leg (-1: automatic, 0 = skip)")
     p.add_argument("--tpp", type=int, default=0)
     p.add_argument("--opt", action="append", default=[], help="name=value engine option (tuning)")
     p.add_argument("--no-roofline", action="store_true")
@@ -40,22 +51,166 @@ def parse():
     return p.parse_args()
 
 
-def cpu_baseline(spec, nsteps):
-    """ESPResSo++-algorithm CPU restatement (oracle/, scalar fp64) timed on this host: the timer
-    brackets run() only, like the GPU leg.  Bounded sample: `nsteps` steps of the same workload."""
+WORKLOAD = ("C5 reactive LJ melt (chain_growth_catalytic shape): %d particles, rho*=%.4g, rc=2.5, skin=0.3, dt=0.005, "
+            "Langevin gamma=5 T=0.5, 4 reactions every %d steps; melted for %d steps before the reactions start")
+
+
+def melted_spec(spec, eng):
+    """The same workload with the engine's current (melted) positions and velocities: what the fp64 leg and
+    the CPU baseline start from.  Types/states are still the initial ones (reactions were off so far)."""
+    s = dict(spec)
+    s["pos"] = eng.get_state("POS")
+    s["vel"] = eng.get_state("VEL")
+    return s
+
+
+def cpu_baseline(spec, nsteps, cores_all):
+    """ESPResSo++-algorithm CPU restatement (oracle/, fp64) timed on this host's cores: the timer brackets
+    run() only, like the GPU leg.  Bounded sample of the same workload; -O3 -march=native -fopenmp build
+    (oracle/Makefile: liboracle_omp.so), once with one thread and once with all cores."""
     from chemlab_amd import workloads as W
     from oracle.oracle import OracleEngine
-    o = OracleEngine()
-    W.apply(spec, o)
-    o.run(0)                      # first list build + force evaluation outside the timer (set-up)
+    res = {}
+    for label, th, ns in (("one_core", 1, max(2, nsteps // 4)), ("all_cores", cores_all, nsteps)):
+        o = OracleEngine(threads=th)
+        W.apply(spec, o)
+        o.run(0)                      # first list build + force evaluation outside the timer (set-up)
+        r0 = o.timers()["rebuilds"]
+        t0 = time.perf_counter()
+        o.run(ns)
+        dt = time.perf_counter() - t0
+        res[label] = dict(value=ns / dt, steps=ns, rebuilds=o.timers()["rebuilds"] - r0, cores=th)
+        o.close()
+    a, b = res["all_cores"], res["one_core"]
+    return dict(value=a["value"], unit="steps/s", cores=a["cores"], kind="port",
+                sample="%d steps (%d list rebuilds inside, no reaction interval) of the same melted %d-particle workload, "
+                       "oracle/md_oracle.cpp built -O3 -march=native -fopenmp, OpenMP over cells; one core: %d steps (%d rebuilds)"
+                       % (a["steps"], a["rebuilds"], spec["n"], b["steps"], b["rebuilds"]),
+                one_core=dict(value=b["value"], unit="steps/s", cores=1))
+
+
+def kernel_rooflines(a, tm, steps_per_s, precision):
+    """HBM-roofline figures of the per-step kernels from the HIP-event samples of the timed region.
+    Algorithmic bytes per particle, restated for this build's layout as 8d demands:
+      pair force  B = 16 (x_i) + w<nb> + 4 (count) + 16 (f4) with w = 2 bytes per entry (16-bit tile-local slots)
+                  and <nb> = entries of the force list actually read (pairs that carry a potential);
+                  SURVEY's int32 formula (w = 4) is given beside it;
+      rebuild     B = 16+16 (sort read/write x4) + w<nb> (list write) + 8;
+      integrate   B = 80 (read x4,v4,f4; write x4,v4), x2 in fp64."""
+    n = float(a.n)
+    rb = 2.0 if precision == 64 else 1.0      # fp64 parity mode doubles the x/v/f terms
+    nb = tm["nlist_entries"] / n
+    out = []
+
+    def entry(name, ms, launches, bpp, extra):
+        if launches <= 0:
+            return None
+        avg_s = 1e-3 * ms / launches
+        ach = n * bpp / avg_s
+        d = dict(kernel=name, bound="hbm", achieved=ach / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s", frac=ach / HBM_PEAK,
+                 avg_launch_us=avg_s * 1e6, launches_sampled=int(launches), algorithmic_bytes_per_particle=bpp)
+        d.update(extra)
+        return d
+
+    bpp_pair = 16.0 * rb + 2.0 * nb + 4.0 + 16.0 * rb
+    e = entry("k_pair_tiles", tm["pair_kernel_ms"], tm["pair_kernel_launches"], bpp_pair,
+              dict(mean_neighbours=nb, survey_int32_bytes_per_particle=36.0 + 4.0 * nb))
+    if e:
+        e["frac_survey_int32_formula"] = n * (36.0 + 4.0 * nb) / (e["avg_launch_us"] * 1e-6) / HBM_PEAK
+        out.append(e)
+    bpp_reb = 32.0 * rb + 2.0 * nb + 8.0
+    e = entry("k_rebuild_fused (rebuilding launches)", tm["rebuild_kernel_ms"], tm["rebuild_kernel_launches"], bpp_reb,
+              dict(survey_int32_bytes_per_particle=40.0 + 4.0 * 73.6))
+    if e:
+        e["frac_survey_int32_formula"] = n * (40.0 + 4.0 * 73.6) / (e["avg_launch_us"] * 1e-6) / HBM_PEAK
+        out.append(e)
+    e = entry("k_integrate", tm["integrate_kernel_ms"], tm["integrate_kernel_launches"], 80.0 * rb, {})
+    if e:
+        out.append(e)
+    return out
+
+
+def time_share(tm, steps):
+    """Per-step device time of each kernel class (us), from the sampled launches: the neighbour kernel runs
+    every step (decision only on most, rebuild on some)."""
+    def avg(ms, k):
+        return 1e3 * ms / k if k > 0 else 0.0
+    nsamp = tm["rebuild_kernel_launches"] + tm["decide_kernel_launches"]
+    share = dict(pair=avg(tm["pair_kernel_ms"], tm["pair_kernel_launches"]),
+                 integrate=avg(tm["integrate_kernel_ms"], tm["integrate_kernel_launches"]),
+                 bonded=avg(tm["bonded_kernel_ms"], tm["bonded_kernel_launches"]),
+                 neighbour=1e3 * (tm["rebuild_kernel_ms"] + tm["decide_kernel_ms"]) / nsamp if nsamp else 0.0)
+    return share
+
+
+def load_traffic(n):
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot wrap itself inside bench.py):
+    2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, tools/pmc_traffic.py."""
+    for name in ("round2_kernel_traffic.json", "round1_pair_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            with open(path) as f:
+                tj = json.load(f)
+            if tj.get("particles") == n:
+                return tj, "profiles/" + name
+    return None, None
+
+
+def run_leg(a, spec, precision, local_rank, equil_state=None, steps=None, warmup=None):
+    """One engine through equilibration (or a given melted state), warm-up and the timed region."""
+    from chemlab_amd import workloads as W
+    from chemlab_amd.engine import Engine
+    steps = a.steps if steps is None else steps
+    warmup = a.warmup if warmup is None else warmup
+    eng = Engine(device=local_rank, precision=precision)
+    W.apply(spec if equil_state is None else equil_state, eng)
+    if a.tpp:
+        eng.set_option("tpp", a.tpp)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, float(v))
+    info = {}
+    if equil_state is None:
+        eng.reactions_enable(False)
+        x0 = np.asarray(spec["pos"], dtype=np.float64)
+        eng.run(a.equil)
+        eng.sync()
+        if a.equil > 0:
+            d = eng.get_state("POS_UNFOLDED") - x0
+            info["msd_after_melting"] = float((d * d).sum(1).mean())   # lattice spacing^2 = 1.16: > that means the lattice is gone
+        info["melted"] = melted_spec(spec, eng)
+        eng.reactions_enable(True)
+    eng.run(warmup)
+    eng.sync()
+    ev0 = len(eng.get_events())
+    tm0 = eng.timers()
+    if not a.no_roofline:
+        # HIP events on the launch stream around the per-step kernels of every N-th step of the TIMED region
+        eng.set_option("time_pair_kernel", max(1, steps // 256))
     t0 = time.perf_counter()
-    o.run(nsteps)
+    eng.run(steps)
+    eng.sync()
+    wall = time.perf_counter() - t0
+    tm = eng.timers()
+    eng.set_option("time_pair_kernel", 0)
+    info.update(wall=wall, tm=tm, events=len(eng.get_events()) - ev0, reaction_steps_timed=tm["reaction_steps"] - tm0["reaction_steps"],
+                rebuilds_timed=tm["rebuilds"] - tm0["rebuilds"], reaction_wall_s=tm["reaction_wall_s"] - tm0["reaction_wall_s"])
+    return eng, info
+
+
+def time_reaction_step(eng, interval, ms_per_step):
+    """Advance (untimed) to the step before the next reaction step, then time that one step alone."""
+    togo = (interval - 1) - (eng.step % interval)
+    if togo < 0:
+        togo += interval
+    eng.run(togo)
+    eng.sync()
+    ev0 = len(eng.get_events())
+    t0 = time.perf_counter()
+    eng.run(1)
+    eng.sync()
     dt = time.perf_counter() - t0
-    reb = o.timers()["rebuilds"] - 1
-    o.close()
-    return dict(value=nsteps / dt, unit="steps/s", cores=1, kind="port",
-                sample="%d steps of the same %d-particle reactive melt (%d list rebuilds inside, no reaction interval), oracle/md_oracle.cpp single thread"
-                       % (nsteps, spec["n"], reb))
+    return dict(reaction_step_ms=max(0.0, 1e3 * dt - ms_per_step), reaction_events=len(eng.get_events()) - ev0, at_step=int(eng.step))
 
 
 def main():
@@ -69,68 +224,79 @@ def main():
         else:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
     from chemlab_amd import workloads as W
-    from chemlab_amd.engine import Engine
 
     spec = W.reactive_melt(n=a.n, rho=a.rho, interval=a.interval, seed=2)
     if world > 1 or os.environ.get("CHEM_FORCE_DD"):   # CHEM_FORCE_DD: exercise the RCCL slab path with one rank
         from chemlab_amd import multigpu
         return multigpu.bench_main(a, spec, rank, local_rank, world)
 
-    eng = Engine(device=local_rank, precision=a.precision)
-    W.apply(spec, eng)
-    if a.tpp:
-        eng.set_option("tpp", a.tpp)
-    for kv in a.opt:
-        k, v = kv.split("=")
-        eng.set_option(k, float(v))
-    eng.run(a.warmup)
-    eng.sync()
-    ev0 = len(eng.get_events())
-    if not a.no_roofline:
-        # dominant per-step kernel = pair force: HIP events on the launch stream around every 8th launch
-        # of the TIMED region (the list grows while bonds form, so a sample after the run would be biased)
-        eng.set_option("time_pair_kernel", 8)
-    t0 = time.perf_counter()
-    eng.run(a.steps)
-    eng.sync()
-    wall = time.perf_counter() - t0
-    tm = eng.timers()
-    eng.set_option("time_pair_kernel", 0)
-    nev = len(eng.get_events()) - ev0
+    eng, info = run_leg(a, spec, a.precision, local_rank)
+    wall, tm = info["wall"], info["tm"]
     steps_per_s = a.steps / wall
+    ms_per_step = 1e3 * wall / a.steps
 
     out = dict(metric="MD steps/sec, 1M-particle reactive LJ melt", value=steps_per_s, unit="steps/s",
-               n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * wall / a.steps,
+               n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=ms_per_step,
                higher_is_better=True, scaling="strong", vs_baseline=None,
                dtype="f32" if a.precision == 32 else "f64", data="synthetic",
-               config=dict(workload="C5 reactive LJ melt (chain_growth_catalytic shape): %d particles, rho*=%.4g, rc=2.5, skin=0.3, dt=0.005, Langevin gamma=5 T=0.5, 4 reactions every %d steps"
-                                    % (a.n, a.rho, a.interval),
-                           particles=a.n, reaction_interval=a.interval, reaction_events=nev,
+               config=dict(workload=WORKLOAD % (a.n, a.rho, a.interval, a.equil),
+                           particles=a.n, reaction_interval=a.interval, equilibration_steps=a.equil,
+                           msd_after_melting=info.get("msd_after_melting"),
+                           reaction_steps_timed=int(info["reaction_steps_timed"]), reaction_events=int(info["events"]),
+                           list_rebuilds_timed=int(info["rebuilds_timed"]),
                            tau_per_day=steps_per_s * spec["dt"] * 86400, parallelism="1 GPU, single domain"))
+    if info["reaction_steps_timed"] > 0:
+        out["config"]["reaction_step_ms"] = 1e3 * info["reaction_wall_s"] / info["reaction_steps_timed"]
+    else:
+        # K < interval: the reaction step the metric's name promises is measured on its own, right after the
+        # timed region, and reported beside `value` (never folded into it)
+        r = time_reaction_step(eng, a.interval, ms_per_step)
+        out["config"].update(reaction_step_ms=r["reaction_step_ms"], reaction_events=int(r["reaction_events"]),
+                             reaction_step_measured_separately_at_step=r["at_step"],
+                             steady_state_steps_per_s=a.interval / (a.interval * ms_per_step * 1e-3 + r["reaction_step_ms"] * 1e-3))
 
     if not a.no_roofline:
-        launches = tm["pair_kernel_launches"]          # of the last run() = the timed region
-        avg_s = 1e-3 * tm["pair_kernel_ms"] / max(launches, 1)
-        nb = tm["nlist_entries"] / float(a.n)
-        bytes_per_particle = 36.0 + 4.0 * nb      # B_force = 16 (x_i) + 4<nb> + 4 (count) + 16 (f4)
-        achieved = a.n * bytes_per_particle / avg_s
-        # HBM traffic per launch from the committed PMC passes (rocprofv3 cannot run inside bench.py):
-        # 2 x FETCH_SIZE (gfx950 tallies 128-B requests at 64 B) + WRITE_SIZE, see tools/pmc_traffic.py
-        traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pair_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("particles") == a.n:
-                traffic = tj.get("traffic_bytes_per_launch")
-        out["roofline"] = dict(bound="hbm", kernel="k_pair_tiles", achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
-                               frac=achieved / HBM_PEAK, traffic=traffic, avg_launch_us=avg_s * 1e6, launches=launches,
-                               mean_neighbours=nb, algorithmic_bytes_per_particle=bytes_per_particle,
-                               whole_step_frac=a.n * (bytes_per_particle + 80.0) * steps_per_s / HBM_PEAK)
+        ks = kernel_rooflines(a, tm, steps_per_s, a.precision)
+        share = time_share(tm, a.steps)
+        traffic, src = load_traffic(a.n)
+        for k in ks:
+            key = "k_pair_tiles" if k["kernel"].startswith("k_pair") else ("k_rebuild_fused" if k["kernel"].startswith("k_rebuild") else "k_integrate")
+            k["traffic"] = (traffic or {}).get("traffic_bytes_per_launch", {}).get(key) if isinstance((traffic or {}).get("traffic_bytes_per_launch"), dict) \
+                else ((traffic or {}).get("traffic_bytes_per_launch") if key == "k_pair_tiles" else None)
+            k["traffic_source"] = src if k["traffic"] is not None else None
+        # the dominant kernel = the one with the largest share of the device time per step
+        per_step = dict(k_pair_tiles=share["pair"], k_rebuild_fused=share["neighbour"], k_integrate=share["integrate"])
+        dom = max(per_step, key=per_step.get)
+        main_k = next((k for k in ks if k["kernel"].startswith(dom)), ks[0] if ks else None)
+        if main_k:
+            rl = dict(main_k)
+            rl["device_us_per_step"] = dict(pair=share["pair"], neighbour_kernel=share["neighbour"], integrate=share["integrate"], bonded=share["bonded"])
+            rl["kernels"] = ks
+            nb = tm["nlist_entries"] / float(a.n)
+            rl["whole_step_frac"] = a.n * (36.0 + 2.0 * nb + 80.0) * steps_per_s / HBM_PEAK
+            out["roofline"] = rl
     if a.verbose:
-        print("timers:", json.dumps(eng.timers()), file=sys.stderr)
-    if a.cpu_steps > 0:
-        out["cpu_baseline"] = cpu_baseline(spec, a.cpu_steps)
+        print("timers:", json.dumps(tm), file=sys.stderr)
+    melted = info["melted"]
+    eng.close()
+
+    f64_steps = a.f64_steps if a.f64_steps >= 0 else min(a.steps, 400)
+    if f64_steps > 0 and a.precision == 32:
+        # the reference computes in fp64: the same melted state through the fp64 build of every kernel
+        e64, i64 = run_leg(a, spec, 64, local_rank, equil_state=melted, steps=f64_steps, warmup=min(a.warmup, 50))
+        sps64 = f64_steps / i64["wall"]
+        o64 = dict(value=sps64, unit="steps/s", dtype="f64", steps=f64_steps, ms_per_step=1e3 * i64["wall"] / f64_steps,
+                   reaction_steps_timed=int(i64["reaction_steps_timed"]), list_rebuilds_timed=int(i64["rebuilds_timed"]))
+        if not a.no_roofline:
+            o64["kernels"] = kernel_rooflines(a, i64["tm"], sps64, 64)
+        out["f64"] = o64
+        e64.close()
+
+    if a.cpu_steps != 0:
+        from oracle.oracle import host_cores
+        cores = host_cores()
+        ns = a.cpu_steps if a.cpu_steps > 0 else max(8, int(round(12 * 1.0e6 / a.n * min(cores, 16) / 8.0)))
+        out["cpu_baseline"] = cpu_baseline(melted, ns, cores)
     print(json.dumps(out))
 
 

@@ -65,7 +65,12 @@ class Timers(C.Structure):
                 ("reaction_steps", C.c_int64), ("nlist_entries", C.c_int64),
                 ("nlist_capacity", C.c_int64), ("reaction_wall_s", C.c_double),
                 ("rebuild_wall_s", C.c_double), ("pair_kernel_ms", C.c_double),
-                ("pair_kernel_launches", C.c_int64)]
+                ("pair_kernel_launches", C.c_int64),
+                ("rebuild_kernel_ms", C.c_double), ("rebuild_kernel_launches", C.c_int64),
+                ("decide_kernel_ms", C.c_double), ("decide_kernel_launches", C.c_int64),
+                ("nlist_entries_all", C.c_int64),
+                ("integrate_kernel_ms", C.c_double), ("integrate_kernel_launches", C.c_int64),
+                ("bonded_kernel_ms", C.c_double), ("bonded_kernel_launches", C.c_int64)]
 
 
 _P = C.c_void_p

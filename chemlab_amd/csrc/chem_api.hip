@@ -196,8 +196,13 @@ template <typename R> struct CtxT : Ctx {
   DBuf<ReactSet> rs_dev;
   Box<R> box{}; BoxD boxd{};
   bool device_ready = false;
-  std::vector<hipEvent_t> ev;  // pair-kernel timing events (pairs)
+  // per-kernel HIP-event samples of the timed region (option time_pair_kernel = N: every N-th step)
+  std::vector<hipEvent_t> ev;  // pool, used in pairs
   size_t ev_used = 0;
+  std::vector<int> ev_kind;    // kind of sample k (events 2k, 2k+1): 0 pair, 1 neighbour kernel, 2 integrate, 3 bonded
+  bool timed_step = false;
+  void tbeg(int kind) { if (timed_step && ev_used + 2 <= ev.size()) { HIPCHK(hipEventRecord(ev[ev_used], stream)); ev_kind.push_back(kind); } }
+  void tend() { if (timed_step && ev_used + 2 <= ev.size() && ev_kind.size() == ev_used / 2 + 1) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; } }
 
   CtxT() { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
   ~CtxT() override {
@@ -557,7 +562,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void decide_and_rebuild() {
-    if (use_fused) { launch_rebuild_fused(); return; }
+    if (use_fused) { tbeg(1); launch_rebuild_fused(); tend(); return; }
     hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, kIntPerBlock), 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
     launch_rebuild_chain();
   }
@@ -773,10 +778,10 @@ template <typename R> struct CtxT : Ctx {
     pair_guard = speculative ? 256 : 0;
     pair_subset = subset;
     const int tpp = pick_tpp();
-    const bool timed = opt_time_pair && subset == 0 && (pair_launch_no++ % opt_time_pair) == 0 && ev_used + 2 <= ev.size();
-    if (timed) HIPCHK(hipEventRecord(ev[ev_used], stream));
+    const bool timed = timed_step && subset == 0;
+    if (timed) tbeg(0);
     launch_pair<false>(f4.p, tpp);
-    if (timed) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; }
+    if (timed) tend();
     pair_subset = 0;
     if (subset == 1) { pair_guard = 0; return; }   // interior tiles only: bonded terms follow with the boundary launch
     if (nbent > 0 && (use_fused || dd_on)) {
@@ -786,7 +791,9 @@ template <typename R> struct CtxT : Ctx {
         hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
         bwork_dirty = false;
       }
+      if (timed) tbeg(3);
       hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
+      if (timed) tend();
     } else if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
                          bpar.p, boxd, elist.p, ctl.p, btab_view());
@@ -903,10 +910,11 @@ template <typename R> struct CtxT : Ctx {
     flush_host_state();
     const double t0 = now_s();
     if (opt_time_pair) {
-      const size_t want = (size_t)std::min<int64_t>(2 * (nsteps + 1), 16384);
+      const size_t want = (size_t)std::min<int64_t>(8 * (nsteps / opt_time_pair + 2), 16384);
       while (ev.size() < want) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); ev.push_back(e); }
-      ev_used = 0;
+      ev_used = 0; ev_kind.clear();
     }
+    timed_step = false;
     if (react_on && !reactions.empty() && pin_ev_cap == 0) {
       // pinned staging for the event download: at most one event per two particles; allocated here so
       // that the first reaction step does not pay ~10 ms for it
@@ -931,6 +939,7 @@ template <typename R> struct CtxT : Ctx {
     bool need_int1 = true;
     for (int64_t s = 0; s < nsteps; ++s) {
       if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
+      timed_step = opt_time_pair && (pair_launch_no++ % opt_time_pair) == 0;
       if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
       else { decide_and_rebuild(); compute_forces(); }
       resort = false;   // a rebuild requested by the last reaction step (force_rebuild on the device) has happened by now
@@ -944,23 +953,38 @@ template <typename R> struct CtxT : Ctx {
         if (react_due) react_step();
         need_int1 = true;
       } else {
+        tbeg(2);
         launch_integrate<3>(lang, false, step, 1);
+        tend();
         ++step;
       }
+      timed_step = false;
     }
     check_flags();
     tm.run_wall_s += now_s() - t0;
     tm.steps += nsteps;
     if (opt_time_pair && ev_used) {
-      // Decomposed path: speculative launches that met a pending rebuild leave at once; they are not
+      // Decomposed path: speculative pair launches that met a pending rebuild leave at once; they are not
       // force evaluations, so samples far below the median are dropped from the average.
-      std::vector<float> d;
-      for (size_t k = 0; k + 1 < ev_used; k += 2) { float t = 0; HIPCHK(hipEventElapsedTime(&t, ev[k], ev[k + 1])); d.push_back(t); }
-      std::vector<float> sorted_d(d); std::sort(sorted_d.begin(), sorted_d.end());
-      const float cut = dd_on ? 0.5f * sorted_d[sorted_d.size() / 2] : 0.f;
-      double ms = 0; int64_t cnt = 0;
-      for (float t : d) if (t >= cut) { ms += t; ++cnt; }
-      tm.pair_kernel_ms = ms; tm.pair_kernel_launches = cnt;
+      std::vector<float> d(ev_used / 2);
+      for (size_t k = 0; k < ev_used / 2; ++k) HIPCHK(hipEventElapsedTime(&d[k], ev[2 * k], ev[2 * k + 1]));
+      std::vector<float> pd;
+      for (size_t k = 0; k < d.size(); ++k) if (ev_kind[k] == 0) pd.push_back(d[k]);
+      std::sort(pd.begin(), pd.end());
+      const float cut = (dd_on && !pd.empty()) ? 0.5f * pd[pd.size() / 2] : 0.f;
+      tm.pair_kernel_ms = tm.rebuild_kernel_ms = tm.decide_kernel_ms = tm.integrate_kernel_ms = tm.bonded_kernel_ms = 0;
+      tm.pair_kernel_launches = tm.rebuild_kernel_launches = tm.decide_kernel_launches = tm.integrate_kernel_launches = tm.bonded_kernel_launches = 0;
+      for (size_t k = 0; k < d.size(); ++k) {
+        const float t = d[k];
+        switch (ev_kind[k]) {
+          case 0: if (t >= cut) { tm.pair_kernel_ms += t; tm.pair_kernel_launches++; } break;
+          // the neighbour kernel either only takes the decision (a few us) or rebuilds cells, tiles and lists
+          // (hundreds of us at any size that uses the fused path): told apart by duration
+          case 1: if (t > 0.03f) { tm.rebuild_kernel_ms += t; tm.rebuild_kernel_launches++; } else { tm.decide_kernel_ms += t; tm.decide_kernel_launches++; } break;
+          case 2: tm.integrate_kernel_ms += t; tm.integrate_kernel_launches++; break;
+          default: tm.bonded_kernel_ms += t; tm.bonded_kernel_launches++; break;
+        }
+      }
     }
   }
 

@@ -137,6 +137,18 @@ typedef struct chem_timers {
   double  rebuild_wall_s;          /* host-observed; only reaction-step/forced rebuilds are synchronous */
   double  pair_kernel_ms;          /* HIP-event time of all pair-force launches of the last chem_run */
   int64_t pair_kernel_launches;
+  /* HIP-event samples of the per-step neighbour kernel (k_rebuild_fused) of the last chem_run, split
+   * into launches that rebuilt the lists and launches that only took the decision */
+  double  rebuild_kernel_ms;
+  int64_t rebuild_kernel_launches;
+  double  decide_kernel_ms;
+  int64_t decide_kernel_launches;
+  int64_t nlist_entries_all;       /* pairs within rc+skin before the type-pair filter (0 if unknown) */
+  /* HIP-event samples of the remaining per-step kernels of the last chem_run */
+  double  integrate_kernel_ms;
+  int64_t integrate_kernel_launches;
+  double  bonded_kernel_ms;
+  int64_t bonded_kernel_launches;
 } chem_timers;
 
 /* ---- life cycle ---------------------------------------------------------------------- */

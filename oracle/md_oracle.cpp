@@ -28,12 +28,27 @@
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared (see oracle/Makefile).
 // -ffp-contract=off keeps r^2 = dx*dx+dy*dy+dz*dz free of FMA so the reaction distance
 // test is bit-comparable with the device path.
+//
+// All-core variant (bench.py's cpu_baseline leg, SURVEY 8d "(ii) all physical cores, OpenMP over
+// cells"): the same source built with -O3 -march=native -fopenmp (oracle/Makefile target
+// liboracle_omp.so) and option "threads" > 1.  Then the list build runs over cells in parallel
+// (pairs kept in cell order, deterministic for any thread count, no global sort), the pair-force
+// loop accumulates into per-thread force arrays that are summed afterwards, and the integrator /
+// thermostat loops are plain parallel-for.  With threads == 1 (the default; what every parity test
+// uses) the code path below is the scalar one, unchanged; option "threads"=1 on the OpenMP build
+// runs the threaded code path with one thread (the baseline's 1-core figure: no global pair sort, which
+// is an artefact of this checker, not of the algorithm).
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <ctime>
 #include <map>
 #include <set>
 #include <string>
@@ -109,6 +124,13 @@ struct Orc {
   std::vector<BTable> btables;   // chem_table_create registry (tabulated bonds)
   double e_lj = 0, e_tab = 0, virial = 0;
   double e_list[CHEM_MAX_LISTS] = {0};
+  int threads = 1; bool par = false;   // par: OpenMP code paths (option "threads", also with 1 thread: the baseline's 1-core leg), see the header
+  std::vector<Vec3> fpriv;      // per-thread force arrays of the threaded pair loop
+  // threaded mode: the half list lives in per-thread segments (cell order: segment t, then t+1, ...); their
+  // capacity is reused by every rebuild.  `pairs` is only materialised when something walks the whole list
+  // (reaction step, read-back)
+  std::vector<std::vector<std::pair<int32_t, int32_t>>> parts;
+  bool pairs_stale = false;
 };
 
 static std::string g_err;
@@ -132,7 +154,13 @@ static void fold(Orc& o) {
 }
 
 // Half Verlet list: every unordered pair with r^2 <= (rc+skin)^2 that is not excluded.
+struct Orc;
+static void materialise_pairs(Orc& o);
+static double wall_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+static const bool g_orc_trace = getenv("ORC_TRACE") != nullptr;
+
 static void build_pairs(Orc& o) {
+  const double tb0 = wall_s();
   fold(o);
   o.pairs.clear();
   const double rl = o.rc + o.skin, rl2 = rl * rl;
@@ -162,30 +190,113 @@ static void build_pairs(Orc& o) {
       }
       cells[cid(c[0], c[1], c[2])].push_back(i);
     }
-    for (int cz = 0; cz < nc[2]; ++cz)
-      for (int cy = 0; cy < nc[1]; ++cy)
-        for (int cx = 0; cx < nc[0]; ++cx) {
-          const auto& A = cells[cid(cx, cy, cz)];
-          for (size_t a = 0; a < A.size(); ++a)
-            for (size_t b = a + 1; b < A.size(); ++b) test(A[a], A[b]);
-          // 13 forward neighbours
+    const int ncell = nc[0] * nc[1] * nc[2];
+    if (g_orc_trace) fprintf(stderr, "[orc] fold+cells %.3f s\n", wall_s() - tb0);
+    // pairs of one home cell (own cell + 13 forward neighbours) appended to `out`
+    auto cell_pairs = [&](int c, std::vector<std::pair<int32_t, int32_t>>& out) {
+      const int cx = c % nc[0], cy = (c / nc[0]) % nc[1], cz = c / (nc[0] * nc[1]);
+      auto test_to = [&](int32_t i, int32_t j) {
+        Vec3 d = minimg(o, o.x[i] - o.x[j]);
+        double r2 = d.x * d.x + d.y * d.y + d.z * d.z;
+        if (r2 > rl2) return;
+        int32_t a = std::min(i, j), b = std::max(i, j);
+        if (!o.excl[a].empty() && o.excl[a].count(b)) return;
+        out.emplace_back(a, b);
+      };
+      const auto& A = cells[cid(cx, cy, cz)];
+      for (size_t a = 0; a < A.size(); ++a)
+        for (size_t b = a + 1; b < A.size(); ++b) test_to(A[a], A[b]);
+      for (int dz = -1; dz <= 1; ++dz)
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx) {
+            if (dz < 0 || (dz == 0 && dy < 0) || (dz == 0 && dy == 0 && dx <= 0)) continue;   // 13 forward neighbours
+            int ox = (cx + dx + nc[0]) % nc[0], oy = (cy + dy + nc[1]) % nc[1], oz = (cz + dz + nc[2]) % nc[2];
+            const auto& B = cells[cid(ox, oy, oz)];
+            for (int32_t i : A)
+              for (int32_t j : B) test_to(i, j);
+          }
+    };
+    if (!o.par) {
+      for (int c = 0; c < ncell; ++c) cell_pairs(c, o.pairs);
+    } else {
+#ifdef _OPENMP
+      // OpenMP over cells.  Same pair set as above, organised the way a production CPU code would:
+      // cell-contiguous coordinate copies, the periodic image chosen per neighbour CELL (a shift vector)
+      // instead of per pair, every thread walking a contiguous range of cells and appending to its own
+      // vector; the vectors are concatenated in thread (= cell) order, so the list does not depend on
+      // the number of threads.
+      const int nt = o.threads;
+      std::vector<int32_t> cstart(ncell + 1, 0), order(o.n);
+      for (int c = 0; c < ncell; ++c) cstart[c + 1] = cstart[c] + (int32_t)cells[c].size();
+      std::vector<Vec3> xs(o.n);
+#pragma omp parallel for schedule(static) num_threads(nt)
+      for (int c = 0; c < ncell; ++c)
+        for (size_t k = 0; k < cells[c].size(); ++k) { order[cstart[c] + k] = cells[c][k]; xs[cstart[c] + k] = o.x[cells[c][k]]; }
+      if (g_orc_trace) fprintf(stderr, "[orc] xs/order %.3f s\n", wall_s() - tb0);
+      auto& part = o.parts;
+      part.resize(nt);
+      bool any_excl = false;
+      for (int64_t i = 0; i < o.n && !any_excl; ++i) any_excl = !o.excl[i].empty();
+#pragma omp parallel num_threads(nt)
+      {
+        const int t = omp_get_thread_num();
+        auto& out = part[t];
+        out.clear();
+        if (out.capacity() == 0) out.reserve((size_t)(40.0 * o.n / nt));
+        const int c0 = (int)((int64_t)ncell * t / nt), c1 = (int)((int64_t)ncell * (t + 1) / nt);
+        for (int c = c0; c < c1; ++c) {
+          const int cx = c % nc[0], cy = (c / nc[0]) % nc[1], cz = c / (nc[0] * nc[1]);
+          const int a0 = cstart[c], a1 = cstart[c + 1];
+          auto emit = [&](int32_t i, int32_t j) {
+            const int32_t a = std::min(i, j), b = std::max(i, j);
+            if (any_excl && !o.excl[a].empty() && o.excl[a].count(b)) return;
+            out.emplace_back(a, b);
+          };
+          for (int ia = a0; ia < a1; ++ia)
+            for (int ib = ia + 1; ib < a1; ++ib) {
+              const Vec3 d = xs[ia] - xs[ib];
+              if (d.x * d.x + d.y * d.y + d.z * d.z <= rl2) emit(order[ia], order[ib]);
+            }
           for (int dz = -1; dz <= 1; ++dz)
             for (int dy = -1; dy <= 1; ++dy)
               for (int dx = -1; dx <= 1; ++dx) {
-                if (dz < 0 || (dz == 0 && dy < 0) || (dz == 0 && dy == 0 && dx <= 0)) continue;
-                int ox = (cx + dx + nc[0]) % nc[0], oy = (cy + dy + nc[1]) % nc[1],
-                    oz = (cz + dz + nc[2]) % nc[2];
-                const auto& B = cells[cid(ox, oy, oz)];
-                for (int32_t i : A)
-                  for (int32_t j : B) test(i, j);
+                if (dz < 0 || (dz == 0 && dy < 0) || (dz == 0 && dy == 0 && dx <= 0)) continue;   // 13 forward neighbours
+                int ox = cx + dx, oy = cy + dy, oz = cz + dz;
+                Vec3 sh = {0, 0, 0};   // image of the neighbour cell next to this one
+                if (ox < 0) { ox += nc[0]; sh.x = -o.L[0]; } else if (ox >= nc[0]) { ox -= nc[0]; sh.x = o.L[0]; }
+                if (oy < 0) { oy += nc[1]; sh.y = -o.L[1]; } else if (oy >= nc[1]) { oy -= nc[1]; sh.y = o.L[1]; }
+                if (oz < 0) { oz += nc[2]; sh.z = -o.L[2]; } else if (oz >= nc[2]) { oz -= nc[2]; sh.z = o.L[2]; }
+                const int oc = (int)cid(ox, oy, oz);
+                for (int ia = a0; ia < a1; ++ia) {
+                  const Vec3 xi = xs[ia] - sh;
+                  for (int ib = cstart[oc]; ib < cstart[oc + 1]; ++ib) {
+                    const Vec3 d = xi - xs[ib];
+                    if (d.x * d.x + d.y * d.y + d.z * d.z <= rl2) emit(order[ia], order[ib]);
+                  }
+                }
               }
         }
+      }
+      o.pairs_stale = true;
+      if (g_orc_trace) fprintf(stderr, "[orc] pairs found %.3f s\n", wall_s() - tb0);
+#endif
+    }
   }
-  std::sort(o.pairs.begin(), o.pairs.end());
+  if (g_orc_trace) fprintf(stderr, "[orc] list complete %.3f s\n", wall_s() - tb0);
+  if (!o.par) std::sort(o.pairs.begin(), o.pairs.end());
   o.x0 = o.x;
   o.maxdist = 0;
   o.resort = false;
   o.rebuilds++;
+}
+
+static void materialise_pairs(Orc& o) {
+  if (!o.pairs_stale) return;
+  size_t tot = 0;
+  for (auto& p : o.parts) tot += p.size();
+  o.pairs.clear(); o.pairs.reserve(tot);
+  for (auto& p : o.parts) o.pairs.insert(o.pairs.end(), p.begin(), p.end());
+  o.pairs_stale = false;
 }
 
 // ---- potentials ---------------------------------------------------------------------
@@ -323,16 +434,54 @@ static void bonded_forces(Orc& o) {
 static void update_forces(Orc& o, int64_t istep, int phase) {
   for (auto& f : o.f) f = {0, 0, 0};
   o.e_lj = o.e_tab = o.virial = 0;
-  for (auto& pr : o.pairs) {
-    int32_t i = pr.first, j = pr.second;
-    const PairPot& p = o.pp[o.type[i]][o.type[j]];
-    if (!p.kind) continue;
-    Vec3 d = minimg(o, o.x[i] - o.x[j]);
-    double r2 = d.x * d.x + d.y * d.y + d.z * d.z, ff, e;
-    if (!pair_eval(p, r2, &ff, &e)) continue;
-    o.f[i] = o.f[i] + ff * d; o.f[j] = o.f[j] - ff * d;
-    (p.kind == 1 ? o.e_lj : o.e_tab) += e;
-    o.virial += ff * r2;
+  if (!o.par) {
+    for (auto& pr : o.pairs) {
+      int32_t i = pr.first, j = pr.second;
+      const PairPot& p = o.pp[o.type[i]][o.type[j]];
+      if (!p.kind) continue;
+      Vec3 d = minimg(o, o.x[i] - o.x[j]);
+      double r2 = d.x * d.x + d.y * d.y + d.z * d.z, ff, e;
+      if (!pair_eval(p, r2, &ff, &e)) continue;
+      o.f[i] = o.f[i] + ff * d; o.f[j] = o.f[j] - ff * d;
+      (p.kind == 1 ? o.e_lj : o.e_tab) += e;
+      o.virial += ff * r2;
+    }
+  } else {
+#ifdef _OPENMP
+    // threaded pair loop: contiguous chunks of the (cell-ordered) half list per thread, Newton's third
+    // law into a per-thread force array, arrays summed in thread order afterwards
+    const int nt = o.threads;
+    const int64_t n = o.n;
+    o.fpriv.resize((size_t)nt * n);
+    double elj = 0, etab = 0, vir = 0;
+#pragma omp parallel num_threads(nt) reduction(+ : elj, etab, vir)
+    {
+      const int t = omp_get_thread_num();
+      Vec3* f = o.fpriv.data() + (size_t)t * n;
+      for (int64_t i = 0; i < n; ++i) f[i] = {0, 0, 0};
+      const auto& seg = o.parts[t];   // the segment this thread built (same thread count)
+      const int64_t hi = (int64_t)seg.size();
+      for (int64_t k = 0; k < hi; ++k) {
+        const int32_t i = seg[k].first, j = seg[k].second;
+        const PairPot& p = o.pp[o.type[i]][o.type[j]];
+        if (!p.kind) continue;
+        Vec3 d = minimg(o, o.x[i] - o.x[j]);
+        double r2 = d.x * d.x + d.y * d.y + d.z * d.z, ff, e;
+        if (!pair_eval(p, r2, &ff, &e)) continue;
+        f[i] = f[i] + ff * d; f[j] = f[j] - ff * d;
+        if (p.kind == 1) elj += e; else etab += e;
+        vir += ff * r2;
+      }
+#pragma omp barrier
+#pragma omp for schedule(static)
+      for (int64_t i = 0; i < n; ++i) {
+        Vec3 a = {0, 0, 0};
+        for (int q = 0; q < nt; ++q) a = a + o.fpriv[(size_t)q * n + i];
+        o.f[i] = a;
+      }
+    }
+    o.e_lj = elj; o.e_tab = etab; o.virial = vir;
+#endif
   }
   bonded_forces(o);
   if (o.cap_force > 0) {   // integrator.CapForce, connected before the thermostat (start_simulation.py:320-324)
@@ -342,6 +491,7 @@ static void update_forces(Orc& o, int64_t istep, int phase) {
     }
   }
   if (o.lang) {
+#pragma omp parallel for schedule(static) num_threads(o.threads) if (o.threads > 1)
     for (int64_t i = 0; i < o.n; ++i) {
       uint32_t r[4];
       chem_philox::langevin_draw(o.lang_seed, (uint64_t)istep, (uint32_t)phase, (uint32_t)i, r);
@@ -429,6 +579,7 @@ static void on_new_bonds(Orc& o, const std::vector<std::pair<int32_t, int32_t>>&
 struct Cand { int32_t a, b, r; double d2; uint32_t h; };
 
 static void react(Orc& o) {
+  materialise_pairs(o);
   o.reaction_steps++;
   std::vector<Cand> c;
   for (auto& pr : o.pairs) {
@@ -503,6 +654,7 @@ static void run(Orc& o, int64_t nsteps) {
   update_forces(o, o.step, 0);
   for (int64_t s = 0; s < nsteps; ++s) {
     double max2 = 0;
+#pragma omp parallel for schedule(static) num_threads(o.threads) reduction(max : max2) if (o.threads > 1)
     for (int64_t i = 0; i < o.n; ++i) {
       double hm = 0.5 * o.dt / o.mass[i];
       o.v[i] = o.v[i] + hm * o.f[i];
@@ -515,6 +667,7 @@ static void run(Orc& o, int64_t nsteps) {
     if (o.criterion == 1) o.maxdist = std::sqrt(max2); else o.maxdist += std::sqrt(max2);
     if (o.maxdist > 0.5 * o.skin || o.resort) build_pairs(o);
     update_forces(o, o.step, 1);
+#pragma omp parallel for schedule(static) num_threads(o.threads) if (o.threads > 1)
     for (int64_t i = 0; i < o.n; ++i) o.v[i] = o.v[i] + (0.5 * o.dt / o.mass[i]) * o.f[i];
     o.step++;
     if (o.resc_kind == 1 || (o.resc_kind == 2 && o.step % (int64_t)o.resc_param == 0)) {   // aftIntV, start_simulation.py:341-348
@@ -693,6 +846,13 @@ int orc_topology_register(void* c, int arity, int list, const int32_t* types) {
 int orc_set_option(void* c, const char* name, double value) {
   Orc& o = O(c); std::string k = name ? name : "";
   if (k == "rebuild_criterion") { o.criterion = value != 0 ? 1 : 0; o.resort = true; return 0; }
+  if (k == "threads") {   // all-core CPU baseline (needs the -fopenmp build, otherwise stays scalar)
+#ifdef _OPENMP
+    o.threads = value >= 1 ? (int)value : 1; o.par = true; o.resort = true; return 0;
+#else
+    FAIL(CHEM_ENOTIMPL, "threads: this oracle build has no OpenMP (use liboracle_omp.so)");
+#endif
+  }
   return 0;   // device tuning knobs have no meaning for the scalar restatement
 }
 
@@ -748,6 +908,7 @@ int64_t orc_get_exclusions(void* c, int64_t* out, int64_t cap) {
 int64_t orc_get_verlet_pairs(void* c, int64_t* out, int64_t cap) {
   Orc& o = O(c);
   if (o.resort) build_pairs(o);
+  materialise_pairs(o);
   int64_t n = (int64_t)o.pairs.size();
   if (!out) return n; if (cap < n) FAIL(CHEM_ENOSPC, "pairs cap");
   for (int64_t k = 0; k < n; ++k) { out[2 * k] = o.id[o.pairs[k].first]; out[2 * k + 1] = o.id[o.pairs[k].second]; }
@@ -781,7 +942,7 @@ int orc_compute_forces(void* c) {
   return 0;
 }
 
-int orc_get_timers(void* c, chem_timers* t) { Orc& o = O(c); std::memset(t, 0, sizeof(*t)); t->steps = o.step; t->rebuilds = o.rebuilds; t->reaction_steps = o.reaction_steps; t->nlist_entries = 2 * (int64_t)o.pairs.size(); return 0; }
+int orc_get_timers(void* c, chem_timers* t) { Orc& o = O(c); materialise_pairs(o); std::memset(t, 0, sizeof(*t)); t->steps = o.step; t->rebuilds = o.rebuilds; t->reaction_steps = o.reaction_steps; t->nlist_entries = 2 * (int64_t)o.pairs.size(); return 0; }
 
 }  // extern "C"
 

@@ -36,10 +36,52 @@ def api():
     return _api
 
 
+LIB_OMP = os.path.join(HERE, "liboracle_omp.so")
+_api_omp = None
+
+
+def host_cores():
+    """Cores this process may use (cgroup/affinity aware): what `nproc` prints."""
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def api_omp():
+    """All-core build of the same restatement (-O3 -march=native -fopenmp).  -march=native does not
+    travel between machines, so it is always (re)built on the host that is going to time it."""
+    global _api_omp
+    if _api_omp is None:
+        stamp = LIB_OMP + ".host"
+        here = "%s|%s" % (os.uname().nodename, _cpu_model())
+        if not (os.path.exists(LIB_OMP) and os.path.exists(stamp) and open(stamp).read() == here
+                and os.path.getmtime(LIB_OMP) >= os.path.getmtime(os.path.join(HERE, "md_oracle.cpp"))):
+            subprocess.check_call(["make", "-C", HERE, "-B", "liboracle_omp.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            with open(stamp, "w") as f:
+                f.write(here)
+        _api_omp = _capi.bind(C.CDLL(LIB_OMP), "orc_", _EXTRA)
+    return _api_omp
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "?"
+
+
 class OracleEngine(Engine):
-    def __init__(self):
-        a = api()
+    def __init__(self, threads=0):
+        """threads = 0: the scalar checker every parity test uses.  threads >= 1: the OpenMP build with
+        that many threads (bench.py's cpu_baseline: 1 core and all cores)."""
+        a = api() if threads <= 0 else api_omp()
         super().__init__(api=a, ctx=a.create(), precision=64)
+        if threads >= 1:
+            self.set_option("threads", threads)
 
     def compute_forces(self):
         self._ck(self.api.compute_forces(self.ctx))
