@@ -294,7 +294,9 @@ def main():
 
     if a.cpu_steps != 0:
         from oracle.oracle import host_cores
-        cores = host_cores()
+        # a one-GPU box exposes every core of the host in the affinity mask but grants a 16-core share
+        # (more threads than that only fight each other: 256 threads ran 3.5x SLOWER than one)
+        cores = min(host_cores(), 16 * max(1, a.gpus))
         ns = a.cpu_steps if a.cpu_steps > 0 else max(8, int(round(12 * 1.0e6 / a.n * min(cores, 16) / 8.0)))
         out["cpu_baseline"] = cpu_baseline(melted, ns, cores)
     print(json.dumps(out))

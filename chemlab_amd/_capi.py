@@ -96,6 +96,7 @@ SIGNATURES = {
     "thermostat_langevin": (_i, [_P, _d, _d, _u64]),
     "cap_force": (_i, [_P, _d]),
     "thermostat_rescale": (_i, [_P, _i, _d, _d]),
+    "thermostat_svr": (_i, [_P, _d, _d, _u64]),
     "table_create": (_i, [_P, C.c_int64, _d, _d, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "reaction_init": (_i, [_P, _i, _i, _i, _u64]),
     "reaction_add": (_i, [_P, C.POINTER(ReactionDesc)]),

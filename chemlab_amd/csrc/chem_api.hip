@@ -81,7 +81,8 @@ struct Ctx {
   std::string err;
   int device = 0, prec = 32;
   double L[3] = {0, 0, 0}, rc = 0, skin = 0, dt = 0, cap_force = 0;
-  int resc_kind = 0; double resc_kT = 0, resc_param = 0;   // Berendsen (1) / Isokinetic (2) velocity rescaling
+  int resc_kind = 0; double resc_kT = 0, resc_param = 0;   // Berendsen (1) / Isokinetic (2) velocity rescaling, StochasticVelocityRescaling (3)
+  uint64_t svr_seed = 0;
   HostTopology top;
   std::vector<double> pos0, vel0;  // staged particle data (tag order) until first upload
   int ntypes = 1;
@@ -141,7 +142,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<V4> x4, v4, f4, x4o, v4o, tab, x0;
   DBuf<int> tag, tago, rtag, state, res_id, mol_id;
   DBuf<int4> img4, img4o;
-  DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm;
+  DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm, cell_sub;
   // fused rebuild (single domain, tiles): segment scans + grid barrier state
   DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot; DBuf<GridBar> gbar;
   DBuf<int> tile_cnt, tile_off;   // reaction scan on tiles: candidates per tile, their offsets
@@ -248,7 +249,7 @@ template <typename R> struct CtxT : Ctx {
   // cells, neighbour-list capacity and everything else that depends on box/cutoff/skin
   void setup_geometry() {
     setup_box();
-    cell_cnt.alloc(box.ncell + 1); cell_start.alloc(box.ncell + 1);
+    cell_cnt.alloc(box.ncell + 1); cell_start.alloc(box.ncell + 1); cell_sub.alloc(box.ncell + 2);
     HIPCHK(hipMemsetAsync(cell_cnt.p, 0, sizeof(int) * (box.ncell + 1), stream));
     const double vol = L[0] * L[1] * L[2], rl = rc + skin;
     const double expect = 4.0 / 3.0 * M_PI * rl * rl * rl * (dd_on ? nglob : n) / vol;
@@ -301,7 +302,7 @@ template <typename R> struct CtxT : Ctx {
     a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
     a.cell_cnt = cell_cnt.p; a.cell_of = cell_of.p; a.slot_of = slot_of.p; a.cell_start = cell_start.p; a.cell_loc = cell_loc.p;
-    a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
+    a.cell_sub = cell_sub.p; a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
     a.desc = tdesc.p; a.excl_start = excl_start.p; a.excl_list = excl_list.p; a.nl16 = nl16.p; a.nnh = nnh.p; a.nlist = nlist.p; a.nn = nn.p;
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
     a.bstart = bstart.p; a.bent = bent.p; a.bwork = bwork.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
@@ -538,7 +539,7 @@ template <typename R> struct CtxT : Ctx {
     DevCtl* c = ctl.p;
     const R rl2 = (R)((rc + skin) * (rc + skin));
     if (use_tiles) {
-      hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c);
+      hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c, (const int*)cell_sub.p);
       hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
       hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
                          excl_start.p, excl_list.p, has_excl, act, all_active ? 1 : 0, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
@@ -556,7 +557,7 @@ template <typename R> struct CtxT : Ctx {
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream, box.ncell, 0, cell_cnt.p, cell_start.p, c);
     hipLaunchKernelGGL(k_place, dim3(nb), dim3(256), 0, stream, 0, n, cell_of.p, slot_of.p, cell_start.p, perm.p, c);
     hipLaunchKernelGGL(k_sort_gather<R>, dim3(std::min(cdiv(box.ncell, 4), 2048)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p,
-                       x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
+                       x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c, box, cell_sub.p);
     hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, cell_start.p, 0, box.ncell, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, x0.p, c);
     launch_list_chain();
   }
@@ -635,7 +636,10 @@ template <typename R> struct CtxT : Ctx {
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, stream, box.ncell, G, cell_cnt.p, cell_start.p, c);
     hipLaunchKernelGGL(k_place, dim3(nb), dim3(256), 0, stream, G, npend, cell_of.p, slot_of.p, cell_start.p, perm.p, c);
     hipLaunchKernelGGL(k_sort_gather<R>, dim3(std::min(cdiv(box.ncell, 4), 2048)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p,
-                       x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c);
+                       x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c, box, cell_sub.p);
+    // the ghost layers are filled by the neighbours' particles afterwards: no sub-bin information for their cells
+    hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nxy, 256)), dim3(256), 0, stream, cell_sub.p, -1, (size_t)nxy);
+    hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nxy, 256)), dim3(256), 0, stream, cell_sub.p + (size_t)(ncz + 1) * nxy, -1, (size_t)nxy);
     hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nglob, 256)), dim3(256), 0, stream, rtag.p, -1, (size_t)nglob);
     hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, cell_start.p, nxy, (ncz + 1) * nxy, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, x0.p, c);
     // 5. boundary-layer counts to the neighbours
@@ -896,10 +900,10 @@ template <typename R> struct CtxT : Ctx {
     hipLaunchKernelGGL(k_kinetic<R>, dim3(nkb), dim3(256), 0, stream, G, n, v4.p, ekout.p);
     const bool multi = dd_on && P > 1;
     hipLaunchKernelGGL(k_rescale_lambda, dim3(1), dim3(256), 0, stream, ekout.p, nkb, resc_buf.p, multi ? (double*)nullptr : resc_buf.p + 1,
-                       resc_kind, resc_kT, dt / resc_param, (double)nglob);
+                       resc_kind, resc_kT, dt / resc_param, (double)nglob, svr_seed, (uint64_t)step);
     if (multi) {
       tr->allreduce_sum_f64(resc_buf.p, 1, stream);
-      hipLaunchKernelGGL(k_rescale_lambda, dim3(1), dim3(256), 0, stream, ekout.p, 0, resc_buf.p, resc_buf.p + 1, resc_kind, resc_kT, dt / resc_param, (double)nglob);
+      hipLaunchKernelGGL(k_rescale_lambda, dim3(1), dim3(256), 0, stream, ekout.p, 0, resc_buf.p, resc_buf.p + 1, resc_kind, resc_kT, dt / resc_param, (double)nglob, svr_seed, (uint64_t)step);
     }
     hipLaunchKernelGGL(k_scale_v<R>, dim3(nkb), dim3(256), 0, stream, G, n, v4.p, resc_buf.p + 1);
   }
@@ -949,7 +953,7 @@ template <typename R> struct CtxT : Ctx {
       if (last || react_due || !opt_fuse || resc_kind) {
         launch_integrate<1>(lang, lang, step, 1);
         ++step;
-        if (resc_kind == 1 || (resc_kind == 2 && step % (int64_t)resc_param == 0)) rescale_velocities();
+        if (resc_kind == 1 || resc_kind == 3 || (resc_kind == 2 && step % (int64_t)resc_param == 0)) rescale_velocities();
         if (react_due) react_step();
         need_int1 = true;
       } else {
@@ -1006,9 +1010,12 @@ template <typename R> struct CtxT : Ctx {
     if (dd_on) { cand_loc.alloc((size_t)cand_cap); cnt_all.alloc(64); }
   }
   void react_step() {
-    const double t0 = now_s();
     tm.reaction_steps++;
     if (reactions.empty()) return;
+    // the host runs ahead of the device by up to `interval` steps: drain that backlog first so that
+    // reaction_wall_s measures the reaction step, not the MD steps queued before it
+    HIPCHK(hipStreamSynchronize(stream));
+    const double t0 = now_s();
     join_async();   // labels of the previous reaction step must be on the device before the scan
     alloc_reaction_buffers();
     ReactSet rs{};
@@ -1623,6 +1630,14 @@ int chem_thermostat_rescale(chem_ctx* ctx, int kind, double kT, double param) {
   if (kind == 1) REQUIRE(param > 0, CHEM_EINVAL, "Berendsen: tau must be > 0");
   if (kind == 2) REQUIRE(param >= 1, CHEM_EINVAL, "Isokinetic: coupling must be >= 1 step");
   CTX.resc_kind = kind; CTX.resc_kT = kT; CTX.resc_param = kind == 2 ? std::floor(param) : param;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_thermostat_svr(chem_ctx* ctx, double kT, double coupling, uint64_t seed) {
+  API_BEGIN
+  if (coupling > 0) REQUIRE(kT > 0, CHEM_EINVAL, "thermostat_svr: temperature");
+  CTX.resc_kind = coupling > 0 ? 3 : 0; CTX.resc_kT = kT; CTX.resc_param = coupling; CTX.svr_seed = seed;
   return 0;
   API_END(ctx)
 }

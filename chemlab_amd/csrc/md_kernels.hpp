@@ -398,43 +398,75 @@ __global__ __launch_bounds__(256) void k_place(int i0, int n, const int* __restr
   }
 }
 
-// One wave per cell: rank the members by tag (canonical order inside a cell => the whole pipeline
-// is run-to-run deterministic) and gather the particle arrays into cell-sorted order.
+// One wave per cell: rank the members by (x sub-bin, tag) -- a canonical order inside a cell, so the whole
+// pipeline is run-to-run deterministic -- and gather the particle arrays into cell-sorted order.
+// The cell is cut into NSUB slices along x; cell_sub[c] packs the number of members in front of slice
+// 1, 2, 3 (8 bits each): the list build uses it to test only the x-window of a stencil row that can hold
+// neighbours of a given home particle (dev_nlist_tile).  Crowded cells (> 64 members) keep plain tag
+// order and store -1 ("no sub-bin information": the list build then takes the whole cell).
+constexpr int NSUB = 4;
+template <typename R>
+__device__ __forceinline__ int sort_key(const Vec4<R>& x, int cx, const Box<R>& box, int tg) {
+  const R clx = box.L[0] / (R)(box.nc[0] > 0 ? box.nc[0] : 1);
+  int b = (int)((x.x - (R)cx * clx) * ((R)NSUB / clx));
+  b = b < 0 ? 0 : (b > NSUB - 1 ? NSUB - 1 : b);
+  return (b << 27) | tg;     // tags < 2^27 (chem_set_particles)
+}
 template <typename R>
 __device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start, const int* perm, const Vec4<R>* x4, const Vec4<R>* v4,
-                                                const int* tag, const int4* img4, Vec4<R>* x4o, Vec4<R>* v4o, int* tago, int4* img4o) {
+                                                const int* tag, const int4* img4, Vec4<R>* x4o, Vec4<R>* v4o, int* tago, int4* img4o,
+                                                const Box<R>& box, int* cell_sub) {
   // Two cells per wave (one per half-wave, width-32 shuffles) while both have <= 32 members -- the mean
   // occupancy is ~18 -- otherwise one cell per wave / the global-memory ranking for crowded cells.
   const int l = lane_id(), hl = l & 31, half = l >> 5;
   const int nw = gridDim.x * (blockDim.x >> 6);
+  const int nx = box.nc[0] > 0 ? box.nc[0] : 1;
   for (int c0 = 2 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); c0 < ncell; c0 += 2 * nw) {
     const int s0 = cell_start[c0], s1 = cell_start[c0 + 1], s2 = c0 + 1 < ncell ? cell_start[c0 + 2] : s1;
     const int cnt0 = s1 - s0, cnt1 = s2 - s1;
     if (cnt0 <= 32 && cnt1 <= 32) {
       const int s = half ? s1 : s0, cnt = half ? cnt1 : cnt0, cmax = cnt0 > cnt1 ? cnt0 : cnt1;
-      int pi = 0, tg = 0x7fffffff;
-      if (hl < cnt) { pi = perm[s + hl]; tg = tag[pi]; }
+      const int cc = c0 + half;
+      int pi = 0, tg = 0, key = 0x7fffffff;
+      Vec4<R> xp = mk4<R>(0, 0, 0, 0);
+      if (hl < cnt) { pi = perm[s + hl]; tg = tag[pi]; xp = x4[pi]; key = sort_key<R>(xp, cc % nx, box, tg); }
       int rank = 0;
-      for (int k = 0; k < cmax; ++k) { const int tk = __shfl(tg, k, 32); rank += (k < cnt && tk < tg) ? 1 : 0; }
+      for (int k = 0; k < cmax; ++k) { const int tk = __shfl(key, k, 32); rank += (k < cnt && tk < key) ? 1 : 0; }
+      // members in front of slice 1, 2, 3 (per half-wave)
+      const int bin = key >> 27;
+      unsigned int packed = 0;
+#pragma unroll
+      for (int b = 1; b < NSUB; ++b) {
+        const unsigned long long m = __ballot(hl < cnt && bin < b);
+        packed |= (unsigned int)__popc((unsigned int)(half ? (m >> 32) : m)) << (8 * (b - 1));
+      }
+      if (hl == 0 && cc < ncell && cell_sub) cell_sub[cc] = (int)packed;
       if (hl < cnt) {
         const int dst = s + rank;
-        x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+        x4o[dst] = xp; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
       }
       continue;
     }
     for (int cc = c0; cc < c0 + 2 && cc < ncell; ++cc) {
       const int s = cell_start[cc], cnt = cell_start[cc + 1] - s;
       if (cnt <= 64) {
-        int pi = 0, tg = 0x7fffffff;
-        if (l < cnt) { pi = perm[s + l]; tg = tag[pi]; }
+        int pi = 0, tg = 0, key = 0x7fffffff;
+        Vec4<R> xp = mk4<R>(0, 0, 0, 0);
+        if (l < cnt) { pi = perm[s + l]; tg = tag[pi]; xp = x4[pi]; key = sort_key<R>(xp, cc % nx, box, tg); }
         int rank = 0;
-        for (int k = 0; k < cnt; ++k) { const int tk = __shfl(tg, k); rank += (tk < tg) ? 1 : 0; }
+        for (int k = 0; k < cnt; ++k) { const int tk = __shfl(key, k); rank += (tk < key) ? 1 : 0; }
+        const int bin = key >> 27;
+        unsigned int packed = 0;
+#pragma unroll
+        for (int b = 1; b < NSUB; ++b) packed |= (unsigned int)__popcll(__ballot(l < cnt && bin < b)) << (8 * (b - 1));
+        if (l == 0 && cell_sub) cell_sub[cc] = (int)packed;
         if (l < cnt) {
           const int dst = s + rank;
-          x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+          x4o[dst] = xp; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
         }
       } else {
-        // crowded cell: each lane ranks its members against all others through global memory
+        // crowded cell: each lane ranks its members against all others through global memory (tag order)
+        if (l == 0 && cell_sub) cell_sub[cc] = -1;
         for (int a = l; a < cnt; a += 64) {
           const int pi = perm[s + a], tg = tag[pi];
           int rank = 0;
@@ -452,9 +484,9 @@ __global__ __launch_bounds__(256) void k_sort_gather(int ncell, const int* __res
                                                      const Vec4<R>* __restrict__ x4, const Vec4<R>* __restrict__ v4,
                                                      const int* __restrict__ tag, const int4* __restrict__ img4,
                                                      Vec4<R>* __restrict__ x4o, Vec4<R>* __restrict__ v4o,
-                                                     int* __restrict__ tago, int4* __restrict__ img4o, const DevCtl* ctl) {
+                                                     int* __restrict__ tago, int4* __restrict__ img4o, const DevCtl* ctl, Box<R> box, int* __restrict__ cell_sub) {
   if (!ctl->need_rebuild) return;
-  dev_sort_gather<R>(ncell, cell_start, perm, x4, v4, tag, img4, x4o, v4o, tago, img4o);
+  dev_sort_gather<R>(ncell, cell_start, perm, x4, v4, tag, img4, x4o, v4o, tago, img4o, box, cell_sub);
 }
 
 template <typename R>
@@ -789,6 +821,10 @@ template <typename R> struct TileLDS {
   R rowshy[NROW], rowshz[NROW];
   int hstart[NHSEG], hoff[NHSEG + 1];  // home x-runs: global start, prefix of counts
   int geom[8];                         // hx, hy, hz, total, nhome, hbase, origin cell (10 bits per axis)
+  // list build only: x sub-bin prefixes of every stencil cell (cell_sub, see dev_sort_gather; -1 = unknown),
+  // staged coordinates of the lower corner of stencil cell (0,0,0), cell edges, sub-bins per unit length
+  int cellsub[NROW][SX];
+  R org[3], clen[3], subinv, pad_;
 };
 
 // NOTE: the pointer must stay a plain local derived from the extern array (no integer
@@ -803,7 +839,7 @@ template <typename R> struct TileLDS {
 // of re-deriving them through dependent global loads and three barrier phases.
 template <typename R>
 __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int tile, const int* __restrict__ cell_start,
-                                            const Box<R>& box, DevCtl* ctl) {
+                                            const Box<R>& box, DevCtl* ctl, const int* __restrict__ cell_sub = nullptr) {
   const int nx = box.nc[0], ny = box.nc[1], nz = box.nc[2];
   const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
   const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
@@ -814,7 +850,7 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
   const int t = threadIdx.x;
   if (t < NROW * SX) {
     const int r = t / SX, k = t % SX, ry = r % SY, rz = r / SY;
-    int cnt = 0, g = 0; R shx = 0;
+    int cnt = 0, g = 0, sub = 0; R shx = 0;
     if (ry < hy + 2 && rz < hz + 2 && k < hx + 2) {
       int ox = cx0 - 1 + k, oy = cy0 - 1 + ry, oz = cz0 - 1 + rz;
       R shy = 0, shz = 0;
@@ -824,9 +860,10 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
       else if (oz < 0) { oz += nz; shz = -box.L[2]; } else if (oz >= nz) { oz -= nz; shz = box.L[2]; }
       const int oc = (oz * ny + oy) * nx + ox;
       g = cell_start[oc]; cnt = cell_start[oc + 1] - g;
+      sub = cell_sub ? cell_sub[oc] : -1;
       if (k == 0) { T.rowshy[r] = shy; T.rowshz[r] = shz; }
     } else if (k == 0) { T.rowshy[r] = 0; T.rowshz[r] = 0; }
-    T.cellg[r][k] = g; T.cellshx[r][k] = shx;
+    T.cellg[r][k] = g; T.cellshx[r][k] = shx; T.cellsub[r][k] = sub;
     T.celloff[r][k + 1] = cnt;   // turned into a prefix below
   }
   __syncthreads();
@@ -854,18 +891,26 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
     T.hoff[NHSEG] = ho;
     T.geom[0] = hx; T.geom[1] = hy; T.geom[2] = hz; T.geom[3] = total; T.geom[4] = ho;
     T.geom[6] = cx0 | (cy0 << 10) | (cz0 << 20);   // first home cell (list build: slot of an excluded partner)
+    // geometry of the staged image (list build, x-window of a row).  In z-ghost mode layer l of the slab is the
+    // global layer z0g + l - 1; the staged z of the ghost layers carries shz_lo / shz_hi, which continues the
+    // same affine map across the periodic boundary.
+    const R clx = box.L[0] / (R)nx, cly = box.L[1] / (R)ny, clz = box.L[2] / (R)(zg ? box.nzg : nz);
+    T.clen[0] = clx; T.clen[1] = cly; T.clen[2] = clz;
+    T.org[0] = (R)(cx0 - 1) * clx; T.org[1] = (R)(cy0 - 1) * cly;
+    T.org[2] = (R)(zg ? box.z0g + cz0 - 2 : cz0 - 1) * clz;
+    T.subinv = (R)NSUB / clx; T.pad_ = 0;
   }
   __syncthreads();
 }
 
 template <typename R>
 __global__ __launch_bounds__(128) void k_tile_desc(int ntiles, int CAP, const int* __restrict__ cell_start, Box<R> box,
-                                                   TileLDS<R>* __restrict__ desc, DevCtl* ctl) {
+                                                   TileLDS<R>* __restrict__ desc, DevCtl* ctl, const int* __restrict__ cell_sub) {
   if (!ctl->need_rebuild) return;
   __shared__ TileLDS<R> T;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
-    tile_tables<R>(T, CAP, tile, cell_start, box, ctl);
+    tile_tables<R>(T, CAP, tile, cell_start, box, ctl, cell_sub);
     const int* src = reinterpret_cast<const int*>(&T);
     int* dst = reinterpret_cast<int*>(&desc[tile]);
     for (int k = threadIdx.x; k < (int)(sizeof(TileLDS<R>) / 4); k += blockDim.x) dst[k] = src[k];
@@ -1126,12 +1171,38 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
       //  2. the few hits (~15 %) are peeled off the mask one by one for the type / exclusion /
       //     activity filters and the chunked store.
       // The branchy hit handling no longer sits in the loop that runs 475 times per particle.
+      // x-window of every stencil row: a candidate in row (dy, dz) is at least (dyv, dzv) away in y and z
+      // (distance of the home particle from that row's slab), so only x within sqrt(rl^2 - dyv^2 - dzv^2)
+      // can be a neighbour -- on average 46 % of the 3-cell run.  The cells are sorted by x sub-bin
+      // (dev_sort_gather), whose prefix counts turn the window into a slot range; `weps` absorbs every
+      // rounding difference between the binning arithmetic and this one (bins only prune, the distance test
+      // below decides membership).
+      auto suboff = [&](int r, int f, bool lower) {
+        const int k = f >> 2, j = f & 3;
+        const int base = T.celloff[r][k];
+        if (j == 0) return base;
+        const int pk = T.cellsub[r][k];
+        if (pk < 0) return lower ? base : T.celloff[r][k + 1];
+        return base + ((pk >> (8 * (j - 1))) & 0xff);
+      };
 #pragma unroll 1
       for (int dzy = 0; dzy < 9; ++dzy) {
         const int dz = dzy / 3, dy = dzy - 3 * dz;
         const int r = (lz + dz) * SY + (ly + dy);
-        const int a = T.rowoff[r] + T.celloff[r][lx];
-        int b = T.rowoff[r] + T.celloff[r][lx + 3];
+        // (everything is recomputed per row from the LDS tables: keeping it live across the row loop spills)
+        const R weps = T.clen[0] * (R)2e-4;
+        const R ylo = T.org[1] + (R)(ly + 1) * T.clen[1], zlo = T.org[2] + (R)(lz + 1) * T.clen[2];
+        R ddy = dy == 0 ? xi.y - ylo - weps : (dy == 2 ? ylo + T.clen[1] - xi.y - weps : (R)0);
+        R ddz = dz == 0 ? xi.z - zlo - weps : (dz == 2 ? zlo + T.clen[2] - xi.z - weps : (R)0);
+        ddy = ddy > 0 ? ddy : (R)0; ddz = ddz > 0 ? ddz : (R)0;
+        const R w2 = rl2 - ddy * ddy - ddz * ddz;
+        if (w2 < (R)0) continue;
+        const R ws = (sqrt_r(w2) + weps) * T.subinv, sxi = (xi.x - T.org[0]) * T.subinv;
+        int f_lo = (int)(sxi - ws), f_hi = (int)(sxi + ws);     // truncation == floor where it matters (clamped below at >= 0)
+        f_lo = f_lo > lx * NSUB ? f_lo : lx * NSUB;
+        f_hi = f_hi < (lx + 3) * NSUB - 1 ? f_hi : (lx + 3) * NSUB - 1;
+        const int a = T.rowoff[r] + suboff(r, f_lo, true);
+        int b = T.rowoff[r] + suboff(r, f_hi + 1, false);
         b = b < total ? b : total;
         if constexpr (sizeof(R) == 4) {
           // fp32 fast path: 32-candidate segments (16 slot pairs), one 32-bit shift-register mask per
@@ -1695,7 +1766,7 @@ template <typename R> struct FusedArgs {
   double half_skin; R rl2;
   Vec4<R> *x4, *v4, *x4o, *v4o, *x0;
   int *tag, *tago, *rtag; int4 *img4, *img4o;
-  int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot;
+  int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot, *cell_sub;
   TileLDS<R>* desc; const int *excl_start, *excl_list;
   unsigned short* nl16; int *nnh, *nlist, *nn;
   unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
@@ -1800,7 +1871,7 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
   if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[3] = wall_clock64();
 
   // ---- P4: canonical order inside every cell + gather; home-particle count of every tile ----
-  dev_sort_gather<R>(a.ncell, a.cell_start, a.perm, a.x4, a.v4, a.tag, a.img4, a.x4o, a.v4o, a.tago, a.img4o);
+  dev_sort_gather<R>(a.ncell, a.cell_start, a.perm, a.x4, a.v4, a.tag, a.img4, a.x4o, a.v4o, a.tago, a.img4o, a.box, a.cell_sub);
   {
     const int nx = a.box.nc[0], ny = a.box.nc[1], nz = a.box.nc[2];
     const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
@@ -1827,7 +1898,7 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
   }
   for (int tile = b; tile < a.ntiles; tile += NB) {
     __syncthreads();
-    tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl);
+    tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl, a.cell_sub);
     const int* src = reinterpret_cast<const int*>(&T);
     int* dst = reinterpret_cast<int*>(&a.desc[tile]);
     for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
@@ -1899,7 +1970,7 @@ __global__ __launch_bounds__(256) void k_kinetic(int i0, int n, const Vec4<R>* _
 // streaming kernel applies it.  Decomposed path: the fold writes the local Ekin, the ranks sum it
 // (transport all-reduce), k_rescale_lambda is launched with nblk = 0 and reads the sum.
 __global__ __launch_bounds__(256) void k_rescale_lambda(const double* __restrict__ part, int nblk, double* __restrict__ ekin_io, double* __restrict__ lam_out,
-                                                        int kind, double kT, double pref /* dt/tau */, double ntot) {
+                                                        int kind, double kT, double pref /* dt/tau */, double ntot, uint64_t svr_seed, uint64_t step) {
   __shared__ double red[4];
   double ek = 0;
   for (int k = threadIdx.x; k < nblk; k += blockDim.x) ek += part[4 * k];
@@ -1911,7 +1982,9 @@ __global__ __launch_bounds__(256) void k_rescale_lambda(const double* __restrict
     else ek = *ekin_io;
     if (lam_out) {
       const double kTnow = 2.0 * ek / (3.0 * ntot);
-      *lam_out = kind == 1 ? sqrt(1.0 + pref * (kT / kTnow - 1.0)) : sqrt(kT / kTnow);
+      // kind 3: StochasticVelocityRescaling (one scalar draw per step, include/chem_philox.h; taut = tau/dt = 1/pref)
+      *lam_out = kind == 1 ? sqrt(1.0 + pref * (kT / kTnow - 1.0)) : kind == 2 ? sqrt(kT / kTnow)
+               : chem_philox::svr_lambda(svr_seed, step, ek, 1.5 * ntot * kT, (int64_t)(3.0 * ntot), 1.0 / pref);
     }
   }
 }

@@ -140,6 +140,10 @@ class Engine:
         k = {None: 0, 0: 0, "berendsen": 1, 1: 1, "isokinetic": 2, 2: 2}[kind]
         self._ck(self.api.thermostat_rescale(self.ctx, k, float(kT), float(param)))
 
+    def thermostat_svr(self, kT, coupling, seed=0):
+        """StochasticVelocityRescaling: kT, coupling time (same units as dt); coupling <= 0 switches it off."""
+        self._ck(self.api.thermostat_svr(self.ctx, float(kT), float(coupling), int(seed)))
+
     def cap_force(self, max_force):
         self._ck(self.api.cap_force(self.ctx, float(max_force)))
 

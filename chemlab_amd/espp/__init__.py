@@ -602,6 +602,20 @@ class _Isokinetic(object):
         self.system.engine.thermostat_rescale(None, 1.0, 1.0)
 
 
+class _StochasticVelocityRescaling(object):
+    """integrator.StochasticVelocityRescaling(system): .temperature (= T*kb), .coupling (start_simulation.py:337-340)."""
+
+    def __init__(self, system):
+        self.system, self.temperature, self.coupling = system, 0.0, 1.0
+
+    def _connect(self, integrator):
+        seed = self.system.rng.get_seed() if self.system.rng is not None else 0
+        self.system.engine.thermostat_svr(self.temperature, self.coupling, seed)
+
+    def disconnect(self):
+        self.system.engine.thermostat_svr(1.0, 0.0, 0)
+
+
 class _CapForce(object):
     """integrator.CapForce(system, max_force) (start_simulation.py:320-324): conservative force of a particle
     rescaled to |f| = max_force where it exceeds it, before the thermostat's terms."""
@@ -794,7 +808,7 @@ integrator = _ns(
     VelocityVerlet=_VelocityVerlet, LangevinThermostat=_LangevinThermostat, ChemicalReaction=_ChemicalReaction,
     Reaction=_Reaction, PostProcessChangeProperty=_PostProcessChangeProperty,
     TopologyParticleProperties=_TopologyParticleProperties, TopologyManager=_TopologyManager, ExtAnalyze=_ExtAnalyze,
-    StochasticVelocityRescaling=_unsupported("integrator.StochasticVelocityRescaling"),
+    StochasticVelocityRescaling=_StochasticVelocityRescaling,
     BerendsenThermostat=_BerendsenThermostat, BerendsenBarostat=_unsupported("integrator.BerendsenBarostat"),
     Isokinetic=_Isokinetic, LangevinBarostat=_unsupported("integrator.LangevinBarostat"),
     CapForce=_CapForce, RestrictReaction=_unsupported("integrator.RestrictReaction"),

@@ -123,6 +123,10 @@ def main(argv=None, hooks=None, quiet=False):
         th = espressopp.integrator.LangevinThermostat(system)
         th.temperature, th.gamma = temperature, args.thermostat_gamma
         integrator.addExtension(th)
+    elif args.thermostat == "vr":                         # start_simulation.py:337-340
+        th = espressopp.integrator.StochasticVelocityRescaling(system)
+        th.temperature, th.coupling = temperature, args.thermostat_gamma
+        integrator.addExtension(th)
     elif args.thermostat == "br":                         # start_simulation.py:341-344
         th = espressopp.integrator.BerendsenThermostat(system)
         th.temperature, th.tau = temperature, args.thermostat_gamma
@@ -132,7 +136,7 @@ def main(argv=None, hooks=None, quiet=False):
         th.temperature, th.coupling = temperature, int(args.thermostat_gamma)
         integrator.addExtension(th)
     elif args.thermostat != "no":
-        raise NotImplementedError("thermostat '%s' is outside the hot-path scope ('lv', 'br', 'iso' or 'no')" % args.thermostat)
+        raise Exception("Wrong thermostat keyword: `%s`" % args.thermostat)   # start_simulation.py:351-352
     # topology manager wiring (start_simulation.py:378-441): spawned angles land in the dynamic Types list
     for name, (fl, inter) in list(bonded.items()):
         dynamic_exclusion_list.observe_tuple(fl)

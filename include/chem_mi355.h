@@ -219,6 +219,12 @@ int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t se
  *   kind 2 Isokinetic: v *= sqrt(kT/kT_now) every `param` steps                       (param = coupling, >= 1)
  *   kind 0 switches it off.  Independent of chem_thermostat_langevin (the driver uses one of them). */
 int chem_thermostat_rescale(chem_ctx* ctx, int kind, double kT, double param);
+/* integrator.StochasticVelocityRescaling(system) (.temperature, .coupling) -- start_simulation.py:337-340
+ * (`thermostat = vr`): every step after the second half kick, v *= sqrt(K_new / K) with K_new drawn from the
+ * canonical kinetic-energy distribution relaxing with time constant `coupling` (Bussi-Donadio-Parrinello 2007;
+ * 3 N degrees of freedom; stream keyed (seed, step), include/chem_philox.h svr_lambda).  coupling <= 0 switches it
+ * off.  Shares the slot of chem_thermostat_rescale (the last call of either wins). */
+int chem_thermostat_svr(chem_ctx* ctx, double kT, double coupling, uint64_t seed);
 /* integrator.CapForce(system, max_force), added before the thermostat -- start_simulation.py:320-324
  * (`max_force`, app_args default -1 = off): after every force evaluation the conservative force of a
  * particle is rescaled to |f| = max_force where it exceeds it; the thermostat's friction and noise come

@@ -119,7 +119,8 @@ struct Orc {
   std::vector<std::pair<int32_t, int32_t>> pairs;  // half Verlet list
   int64_t rebuilds = 0, reaction_steps = 0;
   double cap_force = 0;
-  int resc_kind = 0; double resc_kT = 0, resc_param = 0;   // Berendsen / Isokinetic (chem_thermostat_rescale)
+  int resc_kind = 0; double resc_kT = 0, resc_param = 0;   // Berendsen / Isokinetic (chem_thermostat_rescale), 3 = SVR (chem_thermostat_svr)
+  uint64_t svr_seed = 0;
   struct BTable { double r0, dr; std::vector<double> e, f; };
   std::vector<BTable> btables;   // chem_table_create registry (tabulated bonds)
   double e_lj = 0, e_tab = 0, virial = 0;
@@ -670,11 +671,14 @@ static void run(Orc& o, int64_t nsteps) {
 #pragma omp parallel for schedule(static) num_threads(o.threads) if (o.threads > 1)
     for (int64_t i = 0; i < o.n; ++i) o.v[i] = o.v[i] + (0.5 * o.dt / o.mass[i]) * o.f[i];
     o.step++;
-    if (o.resc_kind == 1 || (o.resc_kind == 2 && o.step % (int64_t)o.resc_param == 0)) {   // aftIntV, start_simulation.py:341-348
+    if (o.resc_kind == 1 || o.resc_kind == 3 || (o.resc_kind == 2 && o.step % (int64_t)o.resc_param == 0)) {   // aftIntV, start_simulation.py:337-348
       double ek = 0;
       for (int64_t i = 0; i < o.n; ++i) ek += 0.5 * o.mass[i] * dot(o.v[i], o.v[i]);
       const double kTnow = 2.0 * ek / (3.0 * (double)o.n);
-      const double lam = o.resc_kind == 1 ? std::sqrt(1.0 + o.dt / o.resc_param * (o.resc_kT / kTnow - 1.0)) : std::sqrt(o.resc_kT / kTnow);
+      const double lam = o.resc_kind == 1 ? std::sqrt(1.0 + o.dt / o.resc_param * (o.resc_kT / kTnow - 1.0))
+                       : o.resc_kind == 2 ? std::sqrt(o.resc_kT / kTnow)
+                       // StochasticVelocityRescaling: 3N degrees of freedom, K_ref = 3N kT / 2, taut = coupling / dt
+                       : chem_philox::svr_lambda(o.svr_seed, (uint64_t)o.step, ek, 1.5 * (double)o.n * o.resc_kT, 3 * o.n, o.resc_param / o.dt);
       for (int64_t i = 0; i < o.n; ++i) o.v[i] = lam * o.v[i];
     }
     if (o.react_on && o.interval > 0 && o.step % o.interval == 0) react(o);
@@ -819,6 +823,11 @@ int orc_thermostat_rescale(void* c, int kind, double kT, double param) {
   if (kind < 0 || kind > 2 || (kind && !(kT > 0)) || (kind == 1 && !(param > 0)) || (kind == 2 && param < 1)) FAIL(CHEM_EINVAL, "thermostat_rescale");
   o.resc_kind = kind; o.resc_kT = kT; o.resc_param = kind == 2 ? std::floor(param) : param; return 0;
 }
+int orc_thermostat_svr(void* c, double kT, double coupling, uint64_t seed) {
+  Orc& o = O(c);
+  if (coupling > 0 && !(kT > 0)) FAIL(CHEM_EINVAL, "thermostat_svr");
+  o.resc_kind = coupling > 0 ? 3 : 0; o.resc_kT = kT; o.resc_param = coupling; o.svr_seed = seed; return 0;
+}
 int orc_cap_force(void* c, double max_force) { O(c).cap_force = max_force > 0 ? max_force : 0; return 0; }
 int orc_thermostat_langevin(void* c, double kT, double gamma, uint64_t seed) {
   Orc& o = O(c); o.lang = (gamma > 0 && kT >= 0); o.kT = kT; o.gamma = gamma; o.lang_seed = seed; return 0;
@@ -945,6 +954,11 @@ int orc_compute_forces(void* c) {
 int orc_get_timers(void* c, chem_timers* t) { Orc& o = O(c); materialise_pairs(o); std::memset(t, 0, sizeof(*t)); t->steps = o.step; t->rebuilds = o.rebuilds; t->reaction_steps = o.reaction_steps; t->nlist_entries = 2 * (int64_t)o.pairs.size(); return 0; }
 
 }  // extern "C"
+
+// one StochasticVelocityRescaling factor (tests/test_oracle_analytic.py)
+extern "C" double orc_svr_lambda(uint64_t seed, uint64_t step, double K, double K_ref, int64_t ndeg, double taut) {
+  return chem_philox::svr_lambda(seed, step, K, K_ref, ndeg, taut);
+}
 
 // raw Philox block for the known-answer test (tests/test_philox.py)
 extern "C" void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {

@@ -41,11 +41,30 @@ _api_omp = None
 
 
 def host_cores():
-    """Cores this process may use (cgroup/affinity aware): what `nproc` prints."""
+    """Cores this process may actually use: the affinity mask (what `nproc` prints) capped by the cgroup CPU
+    quota when one is set (a GPU box shows every core of the host but grants a share of them)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / float(per) + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    cap = os.environ.get("CHEM_CPU_BASELINE_CORES")   # explicit override
+    if cap:
+        n = max(1, int(cap))
+    return n
 
 
 def api_omp():

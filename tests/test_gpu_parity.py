@@ -844,3 +844,27 @@ def test_rescaling_thermostats_match_oracle(make_gpu, make_oracle, kind, param, 
         e.thermostat_rescale(None, 1.0, 1.0)
     g.run(10); o.run(10)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", [None, "dd_self"])
+def test_stochastic_velocity_rescaling_matches_oracle(make_gpu, make_oracle, transport):
+    """SURVEY f-1: StochasticVelocityRescaling (thermostat = vr): kinetic-energy reduction, ONE keyed scalar draw per step
+    on the device (include/chem_philox.h svr_lambda, the same code the oracle runs), scaling pass."""
+    spec = W.lj_melt(n=8788, seed=33, jitter=0.08, kT=1.5)
+    spec["rebuild_criterion"] = 0
+    g, o = make_gpu(64), make_oracle()
+    if transport:
+        g.set_option(transport, 1)
+    W.apply(spec, g, thermostat=False); W.apply(spec, o, thermostat=False)
+    for e in (g, o):
+        e.thermostat_svr(0.9, 0.05, 5)
+    g.run(60); o.run(60)
+    assert g.observe()["temperature"] == pytest.approx(o.observe()["temperature"], rel=1e-9)
+    assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < 1e-8
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+    assert abs(g.observe()["temperature"] - 0.9) < 0.1        # it does thermostat (started at 1.5)
+    for e in (g, o):
+        e.thermostat_svr(0.9, 0.0, 5)
+    g.run(10); o.run(10)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9

@@ -272,3 +272,49 @@ def test_berendsen_and_isokinetic_rescaling(make_oracle):
     assert np.allclose(vb, lam * va, rtol=1e-12, atol=1e-14)                 # one step: same trajectory, scaled at the end
     b.run(400)
     assert b.observe()["temperature"] == pytest.approx(kT0, rel=0.05)        # relaxed to the target
+
+
+def test_stochastic_velocity_rescaling_samples_canonical_kinetic_energy(make_oracle):
+    """integrator.StochasticVelocityRescaling (start_simulation.py:337-340; Bussi-Donadio-Parrinello 2007): the kinetic
+    energy is pulled to the target and FLUCTUATES canonically: <kT> = kT0, var(K)/<K>^2 = 2 / (3N)."""
+    import numpy as np
+    from chemlab_amd import workloads as W
+    spec = W.lj_melt(n=500, seed=4, kT=1.0)
+    kT0, n = 0.6, 500
+    o = make_oracle(); W.apply(spec, o, thermostat=False)
+    o.thermostat_svr(kT0, 0.05, 7)
+    o.run(300)
+    ts = []
+    for _ in range(400):
+        o.run(5)
+        ts.append(o.observe()["temperature"])
+    ts = np.array(ts)
+    assert ts.mean() == pytest.approx(kT0, rel=0.01)
+    assert ts.std() / ts.mean() == pytest.approx(np.sqrt(2.0 / (3 * n)), rel=0.25)
+    # keyed stream: the same seed reproduces the trajectory, another seed does not
+    a, b, c = make_oracle(), make_oracle(), make_oracle()
+    for e, seed in ((a, 11), (b, 11), (c, 12)):
+        W.apply(spec, e, thermostat=False); e.thermostat_svr(kT0, 0.05, seed); e.run(20)
+    assert np.array_equal(a.get_state("VEL"), b.get_state("VEL"))
+    assert not np.allclose(a.get_state("VEL"), c.get_state("VEL"))
+    # coupling <= 0 switches it off: plain NVE afterwards
+    a.thermostat_svr(kT0, 0.0, 11)
+    d = make_oracle(); W.apply(spec, d, thermostat=False)
+    d.set_particles(spec["ids"], spec["types"], a.get_state("POS"), spec["mass"], vel=a.get_state("VEL"))
+    a.run(0); d.run(0)
+    assert np.allclose(a.get_state("FORCE"), d.get_state("FORCE"), rtol=1e-9, atol=1e-9)
+
+
+def test_svr_single_draw_matches_the_formula():
+    """One SVR factor recomputed in numpy from the same Philox stream (include/chem_philox.h svr_lambda): with
+    taut -> infinity the factor is 1, with taut -> 0 the new kinetic energy is K_ref chi^2(ndeg)/ndeg."""
+    import ctypes as C
+    from oracle import oracle
+    lib = C.CDLL(oracle.build())
+    lib.orc_svr_lambda.restype = C.c_double
+    lib.orc_svr_lambda.argtypes = [C.c_uint64, C.c_uint64, C.c_double, C.c_double, C.c_int64, C.c_double]
+    assert lib.orc_svr_lambda(1, 2, 3.0, 5.0, 300, 1e12) == pytest.approx(1.0, abs=1e-5)
+    lams = np.array([lib.orc_svr_lambda(9, s, 2.0, 2.0, 3000, 1e-3) for s in range(2000)])
+    k = 2.0 * lams ** 2          # K_new with instantaneous coupling: K_ref * chi^2(ndeg) / ndeg
+    assert k.mean() == pytest.approx(2.0, rel=2e-3)
+    assert k.std() / k.mean() == pytest.approx(np.sqrt(2.0 / 3000), rel=0.06)
