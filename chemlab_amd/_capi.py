@@ -48,6 +48,12 @@ class ReactionDesc(C.Structure):
     ]
 
 
+class NbChange(C.Structure):
+    _fields_ = [("reaction", C.c_int32), ("invoke_on", C.c_int32), ("old_type", C.c_int32), ("nb_level", C.c_int32),
+                ("new_type", C.c_int32), ("set_state", C.c_int32), ("new_state", C.c_int32), ("pad", C.c_int32),
+                ("new_mass", C.c_double), ("new_q", C.c_double)]
+
+
 class Event(C.Structure):
     _fields_ = [("step", C.c_int64), ("id_a", C.c_int64), ("id_b", C.c_int64),
                 ("reaction", C.c_int32), ("pad", C.c_int32), ("r2", C.c_double)]
@@ -100,6 +106,7 @@ SIGNATURES = {
     "table_create": (_i, [_P, C.c_int64, _d, _d, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "reaction_init": (_i, [_P, _i, _i, _i, _u64]),
     "reaction_add": (_i, [_P, C.POINTER(ReactionDesc)]),
+    "reaction_neighbour_change": (_i, [_P, C.POINTER(NbChange)]),
     "topology_register": (_i, [_P, _i, _i, _pi32]),
     "reactions_enable": (_i, [_P, _i]),
     "reaction_set_rate": (_i, [_P, _i, _d]),

@@ -36,6 +36,33 @@ class SetupReactions(object):
                 self.dynamic_types.update((n2t[old], n2t[new]))
         return r
 
+    def _setup_extension(self, name):
+        """[ext_<name>] -> (post-process object, invoke_on).  In scope: ChangeNeighboursProperty
+        (reaction_post_process.py:76-115: `type_transfers=OLD:level->NEW[(state=1,...)],...`)."""
+        import re
+        cfg = self.cfg["extensions"].get(name)
+        if cfg is None:
+            raise RuntimeError("extension %s is not defined ([ext_%s] missing)" % (name, name))
+        if cfg.get("ext_type") != "ChangeNeighboursProperty":
+            raise NotImplementedError("reaction extension %s (%s) is outside the hot-path scope (SURVEY f-4)" % (name, cfg.get("ext_type")))
+        e, n2t = self.espp, self.name2type
+        pp = e.integrator.PostProcessChangeNeighboursProperty(self.tm)
+        re_opt = re.compile(r"(?P<type_name>\w+)\(?(?P<options>[a-zA-Z0-9_=,]*)\)?")
+        for tr in cfg["type_transfers"].split(","):
+            old, new = tr.split("->")
+            old_type, nb_level = old.split(":")
+            new_type, options = re_opt.match(new).groups()
+            prop = self.topol.gt.atomtypes[new_type]
+            if "state" not in prop:
+                raise RuntimeError("Please define initial atom state in [ atomstate ] section of your topology for atom type %s" % new_type)
+            kw = dict(type=n2t[new_type], mass=prop["mass"], q=prop["charge"], state=prop["state"])
+            for kv in filter(None, options.split(",")):
+                k, v = kv.split("=")
+                kw[k] = int(v) if k in ("state", "type") else float(v)
+            pp.add_change_property(n2t[old_type], e.integrator.TopologyParticleProperties(**kw), int(nb_level))
+            self.dynamic_types.update((n2t[old_type], n2t[new_type]))
+        return pp, cfg.get("invoke_on", "both")
+
     def setup_reactions(self):
         e, g = self.espp, self.cfg["general"]
         ar = e.integrator.ChemicalReaction(self.system, self.vl, self.system.storage, self.tm, g["interval"])
@@ -43,8 +70,7 @@ class SetupReactions(object):
         if g["max_per_interval"] > 0:
             ar.max_per_interval = g["max_per_interval"]
         for gname, group in self.cfg["reactions"].items():
-            if group["extensions"]:
-                raise NotImplementedError("reaction extensions %s (ATRPActivator, ChangeNeighboursProperty, ...) are outside the hot-path scope (SURVEY f-4)" % group["extensions"])
+            group_pp = [(name, self._setup_extension(name)) for name in group["extensions"]]
             fpl = e.FixedPairList(self.system.storage)
             pot_class = getattr(e.interaction, group["potential"])
             pot = pot_class(**group["potential_options"])
@@ -53,5 +79,9 @@ class SetupReactions(object):
             self.system.addInteraction(inter, "fpl_%s" % gname)
             self.fpls.append((gname, fpl, inter))
             for cr in group["reaction_list"]:
-                ar.add_reaction(self._setup_reaction_normal(cr, fpl))
+                r = self._setup_reaction_normal(cr, fpl)
+                for name, (pp, invoke_on) in group_pp:        # reaction_setup.py:495-505
+                    if name not in cr.get("exclude_extensions", []):
+                        r.add_postprocess(pp, invoke_on)
+                ar.add_reaction(r)
         return ar, self.fpls

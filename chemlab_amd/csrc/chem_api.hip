@@ -89,8 +89,9 @@ struct Ctx {
   HostPairPot pp[CHEM_MAX_TYPES][CHEM_MAX_TYPES];
   bool lang = false; double kT = 0, gamma = 0; uint64_t lang_seed = 0;
   bool react_init = false, react_on = false;
-  int interval = 0, nearest = 1; uint64_t react_seed = 0;
+  int interval = 0, nearest = 1, max_per_interval = 0; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
+  std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty (chem_reaction_neighbour_change)
   std::vector<chem_event> events;   // expanded, canonical order (filled lazily from raw_events)
   struct RawEvents { int64_t step; std::vector<int32_t> a, b, r; std::vector<double> d2; };   // SoA copy of the device records
   std::vector<RawEvents> raw_events;  // one block per reaction step, device order
@@ -422,6 +423,7 @@ template <typename R> struct CtxT : Ctx {
     for (int t : top.type) nt = std::max(nt, t + 1);
     for (int a = 0; a < CHEM_MAX_TYPES; ++a) for (int b = 0; b < CHEM_MAX_TYPES; ++b) if (pp[a][b].kind) nt = std::max(nt, std::max(a, b) + 1);
     for (auto& r : reactions) { nt = std::max(nt, std::max(r.new_type_1, r.new_type_2) + 1); }
+    for (auto& r : nb_rules) nt = std::max(nt, r.new_type + 1);
     ntypes = nt;
     std::vector<PairCore<R>> hc((size_t)nt * nt);
     std::vector<PairExt<R>> he((size_t)nt * nt);
@@ -1104,6 +1106,23 @@ template <typename R> struct CtxT : Ctx {
       if (read_ctl().alive == 0) break;
     }
     if (g_trace) { fprintf(stderr, "[chem trace] candidates %d\n", nc); trc.lap("rounds"); }
+    if (max_per_interval > 0) {
+      // ChemicalReaction.max_per_interval (reaction_setup.py:426-427): keep the max_per_interval accepted events of
+      // highest priority (nearest: r^2 then A's tag; random: pair hash then A's tag), as the oracle does.  Rare
+      // option: selection on the host from the downloaded candidate records.
+      std::vector<Candidate> hc; std::vector<int> hs;
+      cand.download(hc, nc, stream);
+      { hs.resize(nc); HIPCHK(hipMemcpyAsync(hs.data(), sin, sizeof(int) * nc, hipMemcpyDeviceToHost, stream)); HIPCHK(hipStreamSynchronize(stream)); }
+      std::vector<int> accd;
+      for (int k = 0; k < nc; ++k) if (hs[k] == 2) accd.push_back(k);
+      if ((int64_t)accd.size() > max_per_interval) {
+        auto key = [&](int k) { return std::make_pair(nearest ? (unsigned long long)reinterpret_cast<const long long&>(hc[k].d2) : (unsigned long long)hc[k].h, hc[k].a); };
+        std::sort(accd.begin(), accd.end(), [&](int p, int q) { return key(p) < key(q); });
+        for (size_t k = (size_t)max_per_interval; k < accd.size(); ++k) hs[accd[k]] = 0;
+        HIPCHK(hipMemcpyAsync(sin, hs.data(), sizeof(int) * nc, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+      }
+    }
     HIPCHK(hipMemsetAsync(evcount.p, 0, sizeof(int), stream));
     hipLaunchKernelGGL(k_react_apply<R>, dim3(ncb), dim3(256), 0, stream, nc, cand.p, sin, ras, state.p, rtag.p, x4.p, v4.p, evout.p, evcount.p);
     int nev = 0;
@@ -1164,7 +1183,7 @@ template <typename R> struct CtxT : Ctx {
         if (d.new_type_2 >= 0 && d.new_type_2 != top.type[e.b]) { top.type[e.b] = d.new_type_2; top.mass[e.b] = d.new_mass_2; top.q[e.b] = d.new_q_2; types_changed = true; }
       }
     };
-    bool mirrors_first = top.spawns_tuples();
+    bool mirrors_first = top.spawns_tuples() || !nb_rules.empty();
     for (auto& l : top.lists) mirrors_first |= l.by_types != 0;
     std::thread mirror_thr;
     std::exception_ptr mirror_err;
@@ -1180,7 +1199,46 @@ template <typename R> struct CtxT : Ctx {
     state_mirror_stale = true;
     if (g_trace) fprintf(stderr, "[chem trace] events %zu new bonds %zu\n", hev.size(), newbonds.size());
     trc.lap("host events");
-    if (!newbonds.empty()) {
+    // PostProcessChangeNeighboursProperty: needs the bond graph with this step's bonds and the mirrors of the new
+    // types; events in canonical order, role 1 before role 2, rules in insertion order (as the oracle)
+    auto neighbour_changes = [&] {
+      if (nb_rules.empty()) return;
+      std::vector<Candidate> ord;
+      for (auto& e : hev) for (auto& rl : nb_rules) if (rl.reaction == e.r) { ord.push_back(e); break; }
+      std::sort(ord.begin(), ord.end(), [&](const Candidate& p, const Candidate& q) { return ekey(p) < ekey(q); });
+      std::vector<HostTopology::PropChange> chg;
+      for (auto& e : ord)
+        for (int role = 1; role <= 2; ++role)
+          for (auto& rl : nb_rules) if (rl.reaction == e.r && (rl.invoke_on & role)) top.neighbour_change(role == 1 ? e.a : e.b, rl, chg);
+      if (chg.empty()) return;
+      static_assert(sizeof(HostTopology::PropChange) == sizeof(PropChangeDev), "layout");
+      DBuf<PropChangeDev> dchg; dchg.alloc(chg.size());
+      HIPCHK(hipMemcpyAsync(dchg.p, chg.data(), chg.size() * sizeof(PropChangeDev), hipMemcpyHostToDevice, stream));
+      hipLaunchKernelGGL((k_apply_props<R>), dim3(cdiv((long long)chg.size(), 256)), dim3(256), 0, stream, (int)chg.size(), dchg.p, state.p, rtag.p, x4.p, v4.p);
+      HIPCHK(hipStreamSynchronize(stream));
+      types_changed = true;
+    };
+    if (!newbonds.empty() && !nb_rules.empty()) {
+      // same dependency order as below, fully synchronous: graph -> (labels on the thread) -> spawned tuples (types as
+      // they are right after the events) -> neighbour property changes -> tables
+      label_bonds = newbonds; label_touched.clear(); labels_pending = true;
+      auto& hs = stage_hs; auto& he = stage_he; auto& hp = stage_hp; auto& es = stage_es; auto& el = stage_el;
+      top.link_new_bonds(newbonds);
+      label_thr = std::thread([this] {
+        try { top.merge_new_bonds(label_bonds, label_touched); } catch (...) { label_err = std::current_exception(); }
+      });
+      top.spawn_for_new_bonds(newbonds);
+      if (label_thr.joinable()) label_thr.join();   // the flood fill reads the graph only; types are not touched by it, but keep it simple
+      neighbour_changes();
+      top.build_excl(es, el);
+      top.build_bonded(hs, he, hp);
+      upload_bonded_from(hs, he, hp);
+      excl_start.upload(es, stream); excl_list.upload(el, stream);
+      HIPCHK(hipStreamSynchronize(stream));
+      has_excl = el.empty() ? 0 : 1; excl_dirty = false;
+      resort = true;
+      set_ctl_field(&DevCtl::force_rebuild, 1);
+    } else if (!newbonds.empty()) {
       // Host work of a bond-forming step, arranged by what depends on what:
       //   bonded CSR  <- lists            exclusion CSR <- exclusions <- (spawned tuples <- graph)
       //   cluster labels <- graph, read again only by the NEXT reaction scan -> host thread, joined lazily
@@ -1219,6 +1277,7 @@ template <typename R> struct CtxT : Ctx {
     }
     if (mirror_thr.joinable()) mirror_thr.join();
     if (mirror_err) std::rethrow_exception(mirror_err);
+    if (newbonds.empty()) neighbour_changes();   // rules on reactions that form no bond
     if (types_changed) { resort = true; set_ctl_field(&DevCtl::force_rebuild, 1); }   // force list depends on types
     if (newbonds.empty() && types_changed) {
       bool any_typed = false;
@@ -1647,8 +1706,8 @@ int chem_cap_force(chem_ctx* ctx, double max_force) { API_BEGIN CTX.cap_force = 
 int chem_reaction_init(chem_ctx* ctx, int interval, int nearest, int max_per_interval, uint64_t seed) {
   API_BEGIN
   REQUIRE(interval > 0, CHEM_EINVAL, "reaction interval must be positive");
-  REQUIRE(max_per_interval <= 0, CHEM_ENOTIMPL, "max_per_interval is outside the hot-path scope (SURVEY f-4)");
   CTX.react_init = true; CTX.interval = interval; CTX.nearest = nearest ? 1 : 0; CTX.react_seed = seed;
+  CTX.max_per_interval = max_per_interval > 0 ? max_per_interval : 0;
   return 0;
   API_END(ctx)
 }
@@ -1667,6 +1726,20 @@ int chem_reaction_add(chem_ctx* ctx, const chem_reaction_desc* d) {
   if (d->new_type_2 >= 0) REQUIRE(d->new_mass_2 > 0, CHEM_EINVAL, "new_mass_2");
   c.reactions.push_back(*d); c.pair_dirty = true;
   return (int)c.reactions.size() - 1;
+  API_END(ctx)
+}
+
+int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* r) {
+  API_BEGIN
+  Ctx& c = CTX;
+  REQUIRE(r, CHEM_EINVAL, "null rule");
+  REQUIRE(r->reaction >= 0 && r->reaction < (int)c.reactions.size(), CHEM_EINVAL, "neighbour_change: reaction index");
+  REQUIRE(r->invoke_on >= 1 && r->invoke_on <= 3 && r->nb_level >= 1, CHEM_EINVAL, "neighbour_change: invoke_on must be 1, 2 or 3 and nb_level >= 1");
+  REQUIRE(r->old_type >= 0 && r->old_type < CHEM_MAX_TYPES && r->new_type >= 0 && r->new_type < CHEM_MAX_TYPES, CHEM_EINVAL, "neighbour_change: types");
+  REQUIRE(r->new_mass > 0, CHEM_EINVAL, "neighbour_change: new_mass");
+  REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "neighbour property changes on the decomposed path");
+  c.nb_rules.push_back(*r); c.pair_dirty = true;
+  return 0;
   API_END(ctx)
 }
 

@@ -239,6 +239,28 @@ struct HostTopology {
     }
   }
 
+  // PostProcessChangeNeighboursProperty (reaction_post_process.py:76-115): particles exactly nb_level bonds away
+  // from `root` whose type is old_type take the new properties.  Mirrors are updated here; the caller pushes the
+  // returned changes to the device arrays.
+  struct PropChange { int32_t tag, type, set_state, state; double mass, q; };
+  std::vector<int32_t> nb_frontier, nb_next;
+  void neighbour_change(int32_t root, const chem_nb_change& rl, std::vector<PropChange>& out) {
+    if (visit_stamp.size() != (size_t)n) { visit_stamp.assign((size_t)n, 0); visit_epoch = 0; }
+    if (++visit_epoch == 0) { std::fill(visit_stamp.begin(), visit_stamp.end(), 0); visit_epoch = 1; }
+    nb_frontier.assign(1, root); visit_stamp[root] = visit_epoch;
+    for (int lvl = 0; lvl < rl.nb_level; ++lvl) {
+      nb_next.clear();
+      for (int32_t p : nb_frontier) for (int32_t nb : graph[p]) if (visit_stamp[nb] != visit_epoch) { visit_stamp[nb] = visit_epoch; nb_next.push_back(nb); }
+      nb_frontier.swap(nb_next);
+    }
+    std::sort(nb_frontier.begin(), nb_frontier.end());
+    for (int32_t p : nb_frontier) {
+      if (type[p] != rl.old_type) continue;
+      type[p] = rl.new_type; mass[p] = rl.new_mass; q[p] = rl.new_q;
+      out.push_back(PropChange{p, rl.new_type, rl.set_state, rl.new_state, rl.new_mass, rl.new_q});
+    }
+  }
+
   // ---- device tables ------------------------------------------------------------------
   // Parameter slots: one per plain list, one per (typed list, type tuple).
   mutable std::vector<int32_t> fill_scratch;   // reused between calls (fresh 4 MB vectors cost their page faults every time)

@@ -2342,6 +2342,19 @@ __global__ void k_react_apply(int nc, const Candidate* __restrict__ c, const int
   out[atomicAdd(out_count, 1)] = cd;
 }
 
+// property changes computed by the host topology manager (PostProcessChangeNeighboursProperty): by tag
+struct PropChangeDev { int tag, type, set_state, state; double mass, q; };
+template <typename R>
+__global__ void k_apply_props(int nchg, const PropChangeDev* __restrict__ chg, int* __restrict__ state, const int* __restrict__ rtag,
+                              Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nchg) return;
+  const PropChangeDev c = chg[k];
+  if (c.set_state) state[c.tag] = c.state;
+  const int i = rtag[c.tag];
+  if (i >= 0) { x4[i].w = (R)c.type; v4[i].w = (R)c.mass; }
+}
+
 template <typename T> __global__ void k_fill(T* p, T v, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;

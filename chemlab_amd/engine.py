@@ -160,6 +160,14 @@ class Engine:
                                bond_list, new_type_1, new_type_2, new_mass_1, new_mass_2, new_q_1, new_q_2)
         return self._ck(self.api.reaction_add(self.ctx, C.byref(d)))
 
+    def reaction_neighbour_change(self, reaction, invoke_on, old_type, nb_level, new_type, new_mass, new_q=0.0, new_state=None):
+        """PostProcessChangeNeighboursProperty rule for the events of `reaction` (index from reaction_add):
+        invoke_on 'type_1' | 'type_2' | 'both'; new_state None keeps the chemical state."""
+        io = {"type_1": 1, "type_2": 2, "both": 3, 1: 1, 2: 2, 3: 3}[invoke_on]
+        r = _capi.NbChange(int(reaction), io, int(old_type), int(nb_level), int(new_type), 0 if new_state is None else 1,
+                           0 if new_state is None else int(new_state), 0, float(new_mass), float(new_q))
+        self._ck(self.api.reaction_neighbour_change(self.ctx, C.byref(r)))
+
     def topology_register(self, h, types):
         t = np.ascontiguousarray(types, dtype=np.int32)
         self._ck(self.api.topology_register(self.ctx, t.shape[0], h, _ptr(t, C.c_int32)))

@@ -636,8 +636,19 @@ class _CapForce(object):
 
 
 class _TopologyParticleProperties(object):
-    def __init__(self, type=None, mass=None, q=None, **kw):
-        self.type, self.mass, self.q = type, mass, q
+    def __init__(self, type=None, mass=None, q=None, state=None, **kw):
+        self.type, self.mass, self.q, self.state = type, mass, q, state
+
+
+class _PostProcessChangeNeighboursProperty(object):
+    """integrator.PostProcessChangeNeighboursProperty(topology_manager).add_change_property(old_type, props, nb_level)
+    (reaction_post_process.py:76-115): attached to a reaction with add_postprocess(pp, 'type_1' | 'type_2' | 'both')."""
+
+    def __init__(self, topology_manager=None):
+        self.rules = []     # (old_type, TopologyParticleProperties, nb_level) in insertion order
+
+    def add_change_property(self, type_id, prop, nb_level):
+        self.rules.append((int(type_id), prop, int(nb_level)))
 
 
 class _PostProcessChangeProperty(object):
@@ -667,6 +678,7 @@ class _Reaction(object):
         self.is_virtual = False
         self.active = True
         self._pp = {}
+        self._nb_pp = []
         self._index = None
         self._system = None
 
@@ -681,6 +693,9 @@ class _Reaction(object):
         raise NotImplementedError("ReactionCutoffRandom is outside the hot-path scope")
 
     def add_postprocess(self, pp, which="type_1"):
+        if isinstance(pp, _PostProcessChangeNeighboursProperty):
+            self._nb_pp.append((pp, which))
+            return
         if not isinstance(pp, _PostProcessChangeProperty):
             raise NotImplementedError("post-process %s is outside the hot-path scope" % type(pp).__name__)
         self._pp[which] = pp
@@ -733,6 +748,10 @@ class _ChemicalReaction(object):
                                       intramolecular=r.intramolecular, intraresidual=r.intraresidual, is_virtual=r.is_virtual,
                                       active=r.active, **kw)
             r._system = self.system
+            for pp, which in r._nb_pp:
+                for old_type, prop, nb_level in pp.rules:
+                    e.reaction_neighbour_change(r._index, which, old_type, nb_level, int(prop.type), float(prop.mass),
+                                                float(prop.q or 0.0), None if prop.state is None else int(prop.state))
 
     def _connect(self, integrator):
         self._flush()
@@ -815,7 +834,7 @@ integrator = _ns(
     DissociationReaction=_unsupported("integrator.DissociationReaction"), ATRPActivator=_unsupported("integrator.ATRPActivator"),
     ReactionCutoffRandom=_unsupported("integrator.ReactionCutoffRandom"), FixDistances=_unsupported("integrator.FixDistances"),
     ChangeInRegion=_unsupported("integrator.ChangeInRegion"), BasicDynamicResolution=_unsupported("integrator.BasicDynamicResolution"),
-    PostProcessChangeNeighboursProperty=_unsupported("integrator.PostProcessChangeNeighboursProperty"),
+    PostProcessChangeNeighboursProperty=_PostProcessChangeNeighboursProperty,
     PostProcessRemoveNeighbourBond=_unsupported("integrator.PostProcessRemoveNeighbourBond"),
     PostProcessJoinParticles=_unsupported("integrator.PostProcessJoinParticles"),
 )

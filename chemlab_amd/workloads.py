@@ -233,7 +233,7 @@ def apply(spec, eng, thermostat=True, reactions=True):
         hb = eng.list_create(2, rx["bond"][0], False)
         eng.list_set_params(hb, rx["bond"][1])
         handles["reaction_bonds"] = hb
-        eng.reaction_init(rx["interval"], rx["nearest"], 0, rx["seed"])
+        eng.reaction_init(rx["interval"], rx["nearest"], rx.get("max_per_interval", 0), rx["seed"])
         for r in rx["reactions"]:
             r = dict(r)
             for k in (1, 2):

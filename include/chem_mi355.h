@@ -240,6 +240,19 @@ int chem_reaction_add(chem_ctx* ctx, const chem_reaction_desc* d);
 /* topology_manager.register_tuple/triplet/quadruplet(list, t1, t2[, t3[, t4]])
  * start_simulation.py:395-440: new bonds spawn entries of `list` when the type tuple matches */
 int chem_topology_register(chem_ctx* ctx, int arity, int list, const int32_t* types);
+/* integrator.PostProcessChangeNeighboursProperty(tm).add_change_property(old_type, TopologyParticleProperties, nb_level),
+ * attached to the reactions of a group by `extensions=` (reaction_post_process.py:76-115, reaction_setup.py:128-165;
+ * examples/atrp_lj/atrp.cfg `type_transfers=MA:2->PA,ML:1->PL(state=1)`).  After the events of a reaction step have
+ * been applied and the new bonds are in the graph, every particle exactly `nb_level` bonds away from a reactant of an
+ * event of `reaction` (invoke_on 1: the type_1 role, 2: the type_2 role, 3: both) whose type is `old_type` gets
+ * new_type / new_mass / new_q and, if set_state != 0, chemical state new_state.  Events are visited in canonical order
+ * (min id, max id), role 1 before role 2, rules in the order they were added. */
+typedef struct chem_nb_change {
+  int32_t reaction, invoke_on, old_type, nb_level;
+  int32_t new_type, set_state, new_state, pad;
+  double  new_mass, new_q;
+} chem_nb_change;
+int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* rule);
 /* integrator.addExtension(ar) / ar.disconnect()  start_simulation.py:735-741,776-777 */
 int chem_reactions_enable(chem_ctx* ctx, int on);
 /* per-reaction rate update (Arrhenius hook, start_simulation.py:785-796) */

@@ -109,6 +109,7 @@ struct Orc {
   bool react_init = false, react_on = false;
   int interval = 0, nearest = 1, max_per_interval = 0; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
+  std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty
   std::vector<chem_event> events;
   // integrator state
   int64_t step = 0;
@@ -628,6 +629,10 @@ static void react(Orc& o) {
   std::vector<char> used(o.n, 0);
   std::vector<Cand> acc;
   for (auto& q : c) { if (used[q.a] || used[q.b]) continue; used[q.a] = used[q.b] = 1; acc.push_back(q); }
+  // ChemicalReaction.max_per_interval (reaction_setup.py:426-427): at most that many events per reaction step.
+  // `acc` is in priority order here (nearest mode: r^2, then A's tag; random mode: pair hash, then A's tag): the
+  // first max_per_interval survive [EXT-RECALL: ESPResSo++ keeps a random subset; this is its deterministic counterpart]
+  if (o.max_per_interval > 0 && (int64_t)acc.size() > o.max_per_interval) acc.resize(o.max_per_interval);
   std::sort(acc.begin(), acc.end(), [](const Cand& p, const Cand& q) {
     return std::make_pair(std::min(p.a, p.b), std::max(p.a, p.b)) < std::make_pair(std::min(q.a, q.b), std::max(q.a, q.b));
   });
@@ -646,6 +651,29 @@ static void react(Orc& o) {
     }
   }
   if (!newbonds.empty()) { on_new_bonds(o, newbonds); o.resort = true; }
+  // PostProcessChangeNeighboursProperty (reaction_post_process.py:76-115): `acc` is in canonical order
+  if (!o.nb_rules.empty()) {
+    std::vector<int32_t> frontier, next;
+    std::set<int32_t> seen;
+    for (auto& q : acc)
+      for (int role = 1; role <= 2; ++role)
+        for (auto& rl : o.nb_rules) {
+          if (rl.reaction != q.r || !(rl.invoke_on & role)) continue;
+          const int32_t root = role == 1 ? q.a : q.b;
+          frontier.assign(1, root); seen.clear(); seen.insert(root);
+          for (int lvl = 0; lvl < rl.nb_level; ++lvl) {   // breadth-first shells of the bond graph
+            next.clear();
+            for (int32_t p : frontier) for (int32_t nb : o.graph[p]) if (seen.insert(nb).second) next.push_back(nb);
+            frontier.swap(next);
+          }
+          std::sort(frontier.begin(), frontier.end());
+          for (int32_t p : frontier) {
+            if (o.type[p] != rl.old_type) continue;
+            o.type[p] = rl.new_type; o.mass[p] = rl.new_mass; o.q[p] = rl.new_q;
+            if (rl.set_state) o.state[p] = rl.new_state;
+          }
+        }
+  }
 }
 
 // ---- integrator ---------------------------------------------------------------------
@@ -835,7 +863,6 @@ int orc_thermostat_langevin(void* c, double kT, double gamma, uint64_t seed) {
 
 int orc_reaction_init(void* c, int interval, int nearest, int max_per_interval, uint64_t seed) {
   Orc& o = O(c); if (interval <= 0) FAIL(CHEM_EINVAL, "interval");
-  if (max_per_interval > 0) FAIL(CHEM_ENOTIMPL, "max_per_interval");
   o.react_init = true; o.interval = interval; o.nearest = nearest; o.max_per_interval = max_per_interval; o.react_seed = seed; return 0;
 }
 
@@ -844,6 +871,14 @@ int orc_reaction_add(void* c, const chem_reaction_desc* d) {
   if (!o.react_init) FAIL(CHEM_ESTATE, "reaction_init first");
   if (!d->is_virtual && (d->bond_list < 0 || d->bond_list >= (int)o.lists.size() || o.lists[d->bond_list].arity != 2)) FAIL(CHEM_EINVAL, "bond_list");
   o.reactions.push_back(*d); return (int)o.reactions.size() - 1;
+}
+
+int orc_reaction_neighbour_change(void* c, const chem_nb_change* r) {
+  Orc& o = O(c);
+  if (!r || r->reaction < 0 || r->reaction >= (int)o.reactions.size() || r->invoke_on < 1 || r->invoke_on > 3 || r->nb_level < 1 ||
+      r->old_type < 0 || r->old_type >= CHEM_MAX_TYPES || r->new_type < 0 || r->new_type >= CHEM_MAX_TYPES || !(r->new_mass > 0))
+    FAIL(CHEM_EINVAL, "reaction_neighbour_change");
+  o.nb_rules.push_back(*r); return 0;
 }
 
 int orc_topology_register(void* c, int arity, int list, const int32_t* types) {

@@ -868,3 +868,43 @@ def test_stochastic_velocity_rescaling_matches_oracle(make_gpu, make_oracle, tra
         e.thermostat_svr(0.9, 0.0, 5)
     g.run(10); o.run(10)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nearest", [True, False])
+def test_max_per_interval_matches_oracle(make_gpu, make_oracle, nearest):
+    """SURVEY f-4: ChemicalReaction.max_per_interval -- the same capped event set on the HIP path and the oracle."""
+    spec = W.reactive_melt(n=8788, seed=15, interval=10)
+    spec["reaction"] = dict(spec["reaction"], max_per_interval=25, nearest=nearest)
+    g, o, h = both(make_gpu, make_oracle, spec, 64)
+    g.run(30); o.run(30)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) == 75
+    assert [e[:4] for e in eg] == [e[:4] for e in eo]
+    assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+    assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+
+
+@pytest.mark.gpu
+def test_change_neighbours_property_matches_oracle(make_gpu, make_oracle):
+    """SURVEY f-4: PostProcessChangeNeighboursProperty on the trimer melt (atrp_lj shape): coupling of two MA ends turns the
+    middle beads (one bond away) into a new type with state 1 and the far ends (two bonds away) into another."""
+    spec = W.trimer_melt(n_mol=216, seed=6, interval=20)
+    MA, ML, PA, PL = 0, 1, 2, 3
+    spec["lj"] += [(PA, t, 1.0, 1.0, spec["rc"]) for t in (MA, ML, PA)] + [(PL, t, 1.0, 1.0, spec["rc"]) for t in (MA, ML, PA, PL)]
+    g, o = make_gpu(64), make_oracle()
+    for e in (g, o):
+        W.apply(spec, e)
+        e.reaction_neighbour_change(0, "both", ML, 1, PL, 1.5, new_state=1)
+        e.reaction_neighbour_change(0, "both", MA, 2, PA, 2.0)
+    g.run(60); o.run(60)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 10 and [e[:4] for e in eg] == [e[:4] for e in eo]
+    tg, to = g.get_state("TYPE"), o.get_state("TYPE")
+    assert (to == PL).sum() > 0 and (to == PA).sum() > 0
+    assert np.array_equal(tg, to)
+    assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+    assert np.allclose(g.get_state("MASS"), o.get_state("MASS"))
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-8

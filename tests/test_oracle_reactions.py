@@ -134,3 +134,45 @@ def test_event_log_is_sorted_and_states_consistent(make_oracle):
     for s in (10, 20, 30):
         ids = [x for (st, a, b, _, _) in ev if st == s for x in (a, b)]
         assert len(ids) == len(set(ids))
+
+
+def test_max_per_interval_keeps_the_highest_priority_events(make_oracle):
+    """ChemicalReaction.max_per_interval (reaction_setup.py:426-427): at most that many events per reaction step --
+    the nearest pairs first (deterministic counterpart of the reference's capped, shuffled list)."""
+    spec = W.reactive_melt(n=4000, seed=14, interval=5)
+    ref = make_oracle(); W.apply(spec, ref)
+    spec2 = dict(spec); spec2["reaction"] = dict(spec["reaction"], max_per_interval=7)
+    cap = make_oracle(); W.apply(spec2, cap)
+    ref.run(5); cap.run(5)
+    e_all, e_cap = ref.get_events(), cap.get_events()
+    assert len(e_all) > 50 and len(e_cap) == 7
+    want = sorted(e_all, key=lambda e: (e["r2"], min(e["id_a"], e["id_b"])))[:7]
+    assert sorted((int(e["id_a"]), int(e["id_b"])) for e in want) == sorted((int(e["id_a"]), int(e["id_b"])) for e in e_cap)
+    cap.run(5)
+    assert len(cap.get_events()) == 14          # the cap holds for every interval
+
+
+def test_change_neighbours_property_on_a_hand_built_chain(make_oracle):
+    """PostProcessChangeNeighboursProperty (reaction_post_process.py:76-115; atrp.cfg `MA:2->PA, ML:1->PL(state=1)`):
+    chain 1-2-3 (types M L M) reacts at bead 3 with a free F bead 4; invoke_on the M role: bead 2 (one bond away, type L)
+    becomes type 4 with state 1, bead 1 (two bonds away, type M) becomes type 3; bead 5-6-7, untouched chain, keeps its types."""
+    M, L, F, P, PL = 0, 1, 2, 3, 4
+    pos = [[3, 5, 5], [4, 5, 5], [5, 5, 5], [5.9, 5, 5], [3, 8, 5], [4, 8, 5], [5, 8, 5]]
+    types = [M, L, M, F, M, L, M]
+    e = setup_small(make_oracle(), pos, types=np.array(types, np.int32), state=np.zeros(7, np.int32), dt=0.001)
+    for a in range(5):
+        for b in range(a, 5):
+            e.nb_lj(a, b, 0.0, 0.0, 2.5, False)
+    chain = e.list_create(2, "HARMONIC"); e.list_set_params(chain, [0.0, 1.0])
+    e.list_add(chain, [[1, 2], [2, 3], [5, 6], [6, 7]])
+    hb = e.list_create(2, "HARMONIC"); e.list_set_params(hb, [0.0, 1.0])
+    e.reaction_init(1, True, 0, 1)
+    r = e.reaction_add(F, M, 1, 1, 0, 1, 0, 1, 1e9, 1.2, bond_list=hb, intramolecular=True)
+    e.reaction_neighbour_change(r, "type_2", L, 1, PL, 2.0, new_state=1)
+    e.reaction_neighbour_change(r, "type_2", M, 2, P, 3.0)
+    e.reactions_enable(True)
+    e.run(1)
+    assert [(int(a), int(b)) for _, a, b, _, _ in sorted_events(e.get_events())] == [(4, 3)]   # (A role = F bead 4, B role = bead 3): bead 3 is the only M within 1.2 of F
+    assert e.get_state("TYPE").tolist() == [P, PL, M, F, M, L, M]
+    assert e.get_state("STATE").tolist() == [0, 1, 1, 1, 0, 0, 0]
+    assert e.get_state("MASS").tolist() == [3.0, 2.0, 1.0, 1.0, 1.0, 1.0, 1.0]
