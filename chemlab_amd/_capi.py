@@ -23,7 +23,7 @@ CHEM_MAX_POT_PARAMS = 6
 OK, EINVAL, ENOSPC, EDEVICE, ESTATE, ENOTIMPL, ECOMM = 0, -1, -2, -3, -4, -5, -6
 PREC_F32, PREC_F64 = 32, 64
 
-POT = dict(HARMONIC=1, FENE=2, TABULATED=3, ANG_HARMONIC=10, ANG_COSINE=11, ANG_TABULATED=12, DIH_NCOS=20, DIH_RB=21, DIH_TABULATED=22)
+POT = dict(HARMONIC=1, FENE=2, TABULATED=3, FENE_LJ=4, LJ_BOND=5, DIH_HARMONIC=23, ANG_HARMONIC=10, ANG_COSINE=11, ANG_TABULATED=12, DIH_NCOS=20, DIH_RB=21, DIH_TABULATED=22)
 STATE = dict(POS=1, VEL=2, FORCE=3, TYPE=4, STATE=5, RESID=6, MASS=7, ID=8, IMAGE=9, MOLID=10,
              POS_UNFOLDED=11)
 

@@ -1,8 +1,9 @@
 """Topology -> particle properties, bonded lists, exclusions and interactions.
 
 Behaviour of /root/reference/src/chemlab/gromacs_topology.py for the in-scope func codes (SURVEY.md
-Appendix B): LJ `func 1`, tabulated `func 8`, harmonic bonds `1`, FENE `7`, harmonic angles `1`,
-cosine angles `11`, dihedrals `1`/`3`.  Type ids: first-seen order over [ molecules ], then the
+Appendix B): LJ `func 1`, tabulated `func 8`, bonds harmonic `1` / FENE `7` / tabulated `8` / FENE+LJ `9`,
+angles harmonic `1` / tabulated `8` / cosine `11`, dihedrals n-cosine `1` / Ryckaert-Bellemans `3` /
+tabulated `8` / harmonic `12`, 1-4 pairs (LJ with fudgeLJ).  Type ids: first-seen order over [ molecules ], then the
 remaining [ atomtypes ] in FILE order (the reference's py2 dict order is not reproducible
 and type ids are internal labels only).  Exclusions: bonds + neighbours up to `nrexcl` bonds away,
 with the atom-id offset per molecule type done correctly (the reference's offset bug is
@@ -199,14 +200,17 @@ def set_bonded_interactions(espressopp, system, gt, dynamic_type_ids=(), table_d
             if not os.path.exists(pot):
                 tables.convert_table(os.path.join(table_dir, "table_b%d.xvg" % int(p[0])), pot)
             return espressopp.interaction.Tabulated(itype=1, filename=pot)
+        if func == 9:                                                           # rMax K sigma epsilon (:935-942)
+            return espressopp.interaction.FENELennardJones(K=p[1], r0=0.0, rMax=p[0], sigma=p[2], epsilon=p[3])
         raise NotImplementedError("bond func %d is outside the hot-path scope" % func)
     for k, ((func, p), bl) in enumerate(groups.items()):
         fpl = espressopp.FixedPairList(system.storage)
         fpl.addBonds(bl)
         cls = {1: espressopp.interaction.FixedPairListHarmonic, 7: espressopp.interaction.FixedPairListFENE,
-               8: espressopp.interaction.FixedPairListTabulated}.get(func)
+               8: espressopp.interaction.FixedPairListTabulated, 9: espressopp.interaction.FixedPairListFENELennardJones}.get(func)
         if cls is None:
             raise NotImplementedError("bond func %d is outside the hot-path scope" % func)
+        fpl.params = (func, list(p))                       # what *_bonds.dat prints for a static list (:1049)
         inter = cls(system, fpl, pot_of(func, p))
         system.addInteraction(inter, "bond_%d" % k)
         out["bond_%d" % k] = (fpl, inter)
@@ -257,6 +261,7 @@ def set_angle_interactions(espressopp, system, gt, dynamic_type_ids=(), table_di
                8: espressopp.interaction.FixedTripleListTabulatedAngular}.get(func)
         if cls is None:
             raise NotImplementedError("angle func %d is outside the hot-path scope" % func)
+        ftl.params = (func, list(p))
         inter = cls(system, ftl, pot_of(func, p))
         system.addInteraction(inter, "angle_%d" % k)
         out["angle_%d" % k] = (ftl, inter)
@@ -273,4 +278,120 @@ def set_angle_interactions(espressopp, system, gt, dynamic_type_ids=(), table_di
             inter.setPotential(ids[0], ids[1], ids[2], pot_of(1, p))
         system.addInteraction(inter, "angle_dynamic")
         out["angle_dynamic"] = (ftl, inter)
+    return out
+
+
+def set_dihedral_interactions(espressopp, system, gt, dynamic_type_ids=(), table_dir="."):
+    """[ dihedrals ] -> FixedQuadrupleList interactions (:1182-1308).  func 1 DihedralHarmonicNCos(K, phi0 rad,
+    multiplicity) from `phi0 K n`; func 3 DihedralRB(K0..K5) from `C0..C5`; func 8 TabulatedDihedral(table_d<N>.pot);
+    func 12 DihedralHarmonic(K, phi0 rad) from `phi0 K`.  Entries whose type tuple can change through a reaction go to
+    ONE Types list per func, the rest are grouped by parameters.
+    (The reference's func 3 conversion drops its first two coefficients, `t = raw[1:]; enumerate(t[1:])` at :1190-1191
+    -- an indexing slip that is not copied: K_n = C_n here.)"""
+    groups, dyn = collections.OrderedDict(), collections.OrderedDict()
+    for ids, prm in gt.dihedrals.items():
+        names = [gt.atoms[i]["type"] for i in ids]
+        spec = {"func": int(prm[0]), "params": prm[1:]} if prm and len(prm) > 1 else _type_params(gt.gt.dihedraltypes, names)
+        if spec is None:
+            raise RuntimeError("no dihedral parameters for %s" % "-".join(names))
+        if any(gt.atoms[i]["type_id"] in dynamic_type_ids for i in ids):
+            dyn.setdefault(spec["func"], []).append(ids)
+        else:
+            groups.setdefault((spec["func"], tuple(float(x) for x in spec["params"])), []).append(ids)
+
+    def pot_of(func, p):
+        if func == 1:
+            return espressopp.interaction.DihedralHarmonicNCos(K=p[1], phi0=p[0] * math.pi / 180.0, multiplicity=int(p[2]))
+        if func == 3:
+            return espressopp.interaction.DihedralRB(*[float(x) for x in p[:6]])
+        if func == 8:
+            pot = os.path.join(table_dir, "table_d%d.pot" % int(p[0]))
+            if not os.path.exists(pot):
+                tables.convert_table(os.path.join(table_dir, "table_d%d.xvg" % int(p[0])), pot)
+            return espressopp.interaction.TabulatedDihedral(itype=1, filename=pot)
+        if func == 12:
+            return espressopp.interaction.DihedralHarmonic(K=p[1], phi0=p[0] * math.pi / 180.0)
+        raise RuntimeError("Unknown func type")                                   # :1203
+    static_cls = {1: "FixedQuadrupleListDihedralHarmonicNCos", 3: "FixedQuadrupleListDihedralRB",
+                  8: "FixedQuadrupleListTabulatedDihedral", 12: "FixedQuadrupleListDihedralHarmonic"}
+    typed_cls = {1: "FixedQuadrupleListTypesDihedralHarmonicNCos", 3: "FixedQuadrupleListTypesDihedralRB",
+                 8: "FixedQuadrupleListTypesTabulatedDihedral", 12: "FixedQuadrupleListTypesDihedralHarmonic"}
+    out = {}
+    for k, ((func, p), ql) in enumerate(groups.items()):
+        if func not in static_cls:
+            raise RuntimeError("Unknown func type")
+        fql = espressopp.FixedQuadrupleList(system.storage)
+        fql.addQuadruples(ql)
+        fql.params = (func, list(p))
+        inter = getattr(espressopp.interaction, static_cls[func])(system, fql, pot_of(func, p))
+        system.addInteraction(inter, "dihedral_%d" % k)
+        out["dihedral_%d" % k] = (fql, inter)
+    # dynamic Types list: also receives the dihedrals that reactions spawn (TopologyManager.register_quadruplet)
+    typed = [(n1, n2, n3, n4, spec) for n1, a in gt.gt.dihedraltypes.items() for n2, b in a.items() for n3, c in b.items()
+             for n4, spec in c.items() if all(n in gt.used_atomsym_atomtype for n in (n1, n2, n3, n4))]
+    funcs = sorted(set(dyn) | ({spec["func"] for *_, spec in typed} if dynamic_type_ids else set()))
+    for func in funcs[:1]:        # one dynamic list (the examples use one dihedral func per topology)
+        fql = espressopp.FixedQuadrupleList(system.storage)
+        fql.addQuadruples(dyn.get(func, []))
+        inter = getattr(espressopp.interaction, typed_cls[func])(system, fql)
+        for n1, n2, n3, n4, spec in typed:
+            if spec["func"] != func:
+                continue
+            ids = [gt.used_atomsym_atomtype[n] for n in (n1, n2, n3, n4)]
+            inter.setPotential(ids[0], ids[1], ids[2], ids[3], pot_of(func, [float(x) if func != 8 else x for x in spec["params"]]))
+        system.addInteraction(inter, "dihedral_dynamic")
+        out["dihedral_dynamic"] = (fql, inter)
+    if len(funcs) > 1:
+        raise NotImplementedError("dynamic dihedrals of more than one functional form in one topology")
+    return out
+
+
+def set_pair_interactions(espressopp, system, gt, lj_cutoff, dynamic_type_ids=()):
+    """[ pairs ] (1-4 interactions) -> FixedPairList[Types]LennardJones (:1314-1411): explicit `sigma epsilon` on the
+    pair line, else [ pairtypes ]-less gen-pairs: combination rule of the two atom types with epsilon * fudgeLJ.
+    (The reference combines atom type 0 with itself, :1341-1342, and calls combination() with three arguments on the
+    static path, :1360 -- SURVEY Q5; here both atom types are used.)"""
+    if not gt.pairs:
+        return {}
+    cr = int(gt.gt.defaults["combinationrule"])
+    fudge = float(gt.gt.defaults.get("fudgeLJ", 1.0))
+    at = gt.gt.atomtypes
+    groups, dyn = collections.OrderedDict(), []
+    for (a, b), prm in gt.pairs.items():
+        n1, n2 = gt.atoms[a]["type"], gt.atoms[b]["type"]
+        if gt.atoms[a]["type_id"] in dynamic_type_ids or gt.atoms[b]["type_id"] in dynamic_type_ids:
+            dyn.append((a, b))
+            continue
+        if prm and len(prm) > 2:
+            sig, eps = float(prm[1]), float(prm[2])
+        else:
+            s1, e1 = convertc6c12(at[n1]["sigma"], at[n1]["epsilon"], cr)
+            s2, e2 = convertc6c12(at[n2]["sigma"], at[n2]["epsilon"], cr)
+            sig, eps = combination(s1, e1, s2, e2, cr)
+            eps *= fudge
+        groups.setdefault((sig, eps), []).append((a, b))
+    out = {}
+    for k, ((sig, eps), bl) in enumerate(groups.items()):
+        fpl = espressopp.FixedPairList(system.storage)
+        fpl.addBonds(bl)
+        fpl.params = (1, [sig, eps])
+        inter = espressopp.interaction.FixedPairListLennardJones(system, fpl, espressopp.interaction.LennardJones(epsilon=eps, sigma=sig, cutoff=lj_cutoff))
+        system.addInteraction(inter, "lj14_%d" % k)
+        out["lj14_%d" % k] = (fpl, inter)
+    if dyn:
+        fpl = espressopp.FixedPairList(system.storage)
+        fpl.addBonds(dyn)
+        inter = espressopp.interaction.FixedPairListTypesLennardJones(system, fpl)
+        names = list(gt.used_atomsym_atomtype)
+        for i, n1 in enumerate(names):
+            for n2 in names[i:]:
+                t1, t2 = gt.used_atomsym_atomtype[n1], gt.used_atomsym_atomtype[n2]
+                if t1 in dynamic_type_ids or t2 in dynamic_type_ids:
+                    s1, e1 = convertc6c12(at[n1]["sigma"], at[n1]["epsilon"], cr)
+                    s2, e2 = convertc6c12(at[n2]["sigma"], at[n2]["epsilon"], cr)
+                    sig, eps = combination(s1, e1, s2, e2, cr)
+                    if sig > 0:
+                        inter.setPotential(t1, t2, espressopp.interaction.LennardJones(sigma=sig, epsilon=fudge * eps, cutoff=lj_cutoff))
+        system.addInteraction(inter, "dyn_lj14")
+        out["lj14_dynamic"] = (fpl, inter)
     return out

@@ -4,7 +4,8 @@ Behaviour of /root/reference/tools/convert_gromacs2espp.py:28-110: non-bonded ta
 (x, e, f).  The kind is taken from the FILE NAME like the reference does (:44-58): `_b<N>` bond,
 `_a<N>` angle, `_d<N>` dihedral; angle and dihedral tables are in degrees and are converted to radians
 (x -> radians(x), f -> f*180/pi, :73-75), keeping 0 < theta <= pi resp. -pi <= phi <= pi (:81-83);
-the r = 0 row of distance tables is dropped; numbers are printed with %15.8g."""
+the r = 0 row of distance tables is dropped; numbers are printed with %15.8g.  Reduced units (:69-72,97-99):
+distances are divided by sigma, energies by epsilon, forces multiplied by sigma/epsilon (angles stay radians)."""
 import math
 import os
 import re
@@ -30,7 +31,7 @@ def convert_table(gro_in, espp_out, sigma=1.0, epsilon=1.0, c6=1.0, c12=1.0):
         r = c[0]
         if angle or dihedral:
             r = math.radians(r)
-            e, f_ = c[1], c[2] * 180.0 / math.pi
+            e, f_ = c[1] / epsilon, c[2] * 180.0 / math.pi * sigma / epsilon
             if (angle and not (0 < r <= math.pi)) or (dihedral and not (-math.pi <= r <= math.pi)):
                 continue
             out.append("%15.8g %15.8g %15.8g\n" % (r, e, f_))
@@ -42,6 +43,7 @@ def convert_table(gro_in, espp_out, sigma=1.0, epsilon=1.0, c6=1.0, c12=1.0):
         else:
             e = c6 * c[3] + c12 * c[5]
             f_ = c6 * c[4] + c12 * c[6]
+        r, e, f_ = r / sigma, e / epsilon, f_ * sigma / epsilon
         out.append("%15.8g %15.8g %15.8g\n" % (r, e, f_))
     with open(espp_out, "w") as f:
         f.writelines(out)

@@ -93,7 +93,8 @@ struct Ctx {
   std::vector<chem_reaction_desc> reactions;
   std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty (chem_reaction_neighbour_change)
   std::vector<chem_event> events;   // expanded, canonical order (filled lazily from raw_events)
-  struct RawEvents { int64_t step; std::vector<int32_t> a, b, r; std::vector<double> d2; };   // SoA copy of the device records
+  struct RawEvents { int64_t step; std::vector<int32_t> a, b, r; std::vector<double> d2; std::vector<int8_t> intra; };   // SoA copy of the device records
+  int opt_intra_inter = 0;   // classify every event as intra-/inter-cluster at event time (ar.save_intra_inter_counter)
   std::vector<RawEvents> raw_events;  // one block per reaction step, device order
   int64_t n_events = 0;
   int64_t step = 0;
@@ -1172,10 +1173,18 @@ template <typename R> struct CtxT : Ctx {
     // bonded-slot resolution and the topology manager; chemical states live on the device).  Events
     // touch disjoint particles, nothing below reads the mirrors unless a list is typed or tuples are
     // spawned, so this runs beside the table builds and is joined at the end of the step.
+    // intra-/inter-cluster flag of every event from the cluster labels as they were BEFORE this step's bonds
+    // (the label thread of the previous reaction step was joined above, this step's has not started yet)
+    std::vector<int8_t> intra_flags;
+    if (opt_intra_inter) {
+      intra_flags.resize(hev.size());
+      for (size_t k = 0; k < hev.size(); ++k) intra_flags[k] = top.mol_id[hev[k].a] == top.mol_id[hev[k].b] ? 1 : 0;
+    }
     auto log_and_mirror = [&] {
       Ctx::RawEvents blk; blk.step = step;
       blk.a.resize(hev.size()); blk.b.resize(hev.size()); blk.r.resize(hev.size()); blk.d2.resize(hev.size());
       for (size_t k = 0; k < hev.size(); ++k) { blk.a[k] = hev[k].a; blk.b[k] = hev[k].b; blk.r[k] = hev[k].r; blk.d2[k] = hev[k].d2; }
+      blk.intra = std::move(intra_flags);
       raw_events.push_back(std::move(blk)); n_events += (int64_t)hev.size();
       for (auto& e : hev) {
         const chem_reaction_desc& d = reactions[e.r];
@@ -1601,9 +1610,9 @@ int chem_nb_table(chem_ctx* ctx, int t1, int t2, int64_t nrow, double r0, double
 int chem_list_create(chem_ctx* ctx, int arity, int kind, int by_types) {
   API_BEGIN
   REQUIRE(arity >= 2 && arity <= 4, CHEM_EINVAL, "list arity must be 2, 3 or 4");
-  const bool ok = (arity == 2 && (kind == CHEM_POT_HARMONIC || kind == CHEM_POT_FENE || kind == CHEM_POT_TABULATED)) ||
+  const bool ok = (arity == 2 && (kind == CHEM_POT_HARMONIC || kind == CHEM_POT_FENE || kind == CHEM_POT_TABULATED || kind == CHEM_POT_FENE_LJ || kind == CHEM_POT_LJ_BOND)) ||
                   (arity == 3 && (kind == CHEM_POT_ANG_HARMONIC || kind == CHEM_POT_ANG_COSINE || kind == CHEM_POT_ANG_TABULATED)) ||
-                  (arity == 4 && (kind == CHEM_POT_DIH_NCOS || kind == CHEM_POT_DIH_RB || kind == CHEM_POT_DIH_TABULATED));
+                  (arity == 4 && (kind == CHEM_POT_DIH_NCOS || kind == CHEM_POT_DIH_RB || kind == CHEM_POT_DIH_TABULATED || kind == CHEM_POT_DIH_HARMONIC));
   REQUIRE(ok, CHEM_ENOTIMPL, "potential kind not supported for this arity");
   REQUIRE((int)CTX.top.lists.size() < CHEM_MAX_LISTS, CHEM_ENOSPC, "too many lists");
   HostList l; l.arity = arity; l.kind = kind; l.by_types = by_types ? 1 : 0;
@@ -1791,7 +1800,7 @@ int64_t chem_get_events(chem_ctx* ctx, chem_event* out, int64_t cap) {
   // expand the raw per-step blocks and put each into canonical order: (step, min id, max id)
   for (auto& blk : c.raw_events) {
     const size_t m = blk.a.size(), first = c.events.size();
-    for (size_t k = 0; k < m; ++k) c.events.push_back(chem_event{blk.step, c.top.id[blk.a[k]], c.top.id[blk.b[k]], blk.r[k], 0, blk.d2[k]});
+    for (size_t k = 0; k < m; ++k) c.events.push_back(chem_event{blk.step, c.top.id[blk.a[k]], c.top.id[blk.b[k]], blk.r[k], blk.intra.empty() ? 0 : (int32_t)blk.intra[k], blk.d2[k]});
     std::sort(c.events.begin() + first, c.events.end(), [](const chem_event& p, const chem_event& q) {
       return std::make_pair(std::min(p.id_a, p.id_b), std::max(p.id_a, p.id_b)) < std::make_pair(std::min(q.id_a, q.id_b), std::max(q.id_a, q.id_b));
     });
@@ -1853,6 +1862,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
     REQUIRE(chem_comm_unique_id(uid) == 0, CHEM_ECOMM, "cannot create an RCCL unique id");
     CTX.tr.reset(new RcclTransport(1, 0, uid)); CTX.dd_on = true; CTX.P = 1; CTX.rk = 0; CTX.geom_dirty = true;
   }
+  else if (k == "count_intra_inter") CTX.opt_intra_inter = value != 0;
   else if (k == "skip_inactive_pairs") { CTX.opt_skip_inactive = value != 0; CTX.pair_dirty = true; }
   else throw ChemError(CHEM_EINVAL, "unknown option " + k);
   return 0;

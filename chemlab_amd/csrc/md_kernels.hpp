@@ -405,12 +405,22 @@ __global__ __launch_bounds__(256) void k_place(int i0, int n, const int* __restr
 // neighbours of a given home particle (dev_nlist_tile).  Crowded cells (> 64 members) keep plain tag
 // order and store -1 ("no sub-bin information": the list build then takes the whole cell).
 constexpr int NSUB = 4;
+// key = x slice (2 bits) | y half | z half | tag: x-major so that cell_sub stays a prefix over the x slices; the
+// y/z halves make neighbouring lanes of the force kernel (consecutive home particles) spatial neighbours, whose
+// slot-sorted lists then read nearby LDS slots in the same instruction (fewer bank conflicts, more broadcasts)
 template <typename R>
-__device__ __forceinline__ int sort_key(const Vec4<R>& x, int cx, const Box<R>& box, int tg) {
-  const R clx = box.L[0] / (R)(box.nc[0] > 0 ? box.nc[0] : 1);
+__device__ __forceinline__ int sort_key(const Vec4<R>& x, int c, const Box<R>& box, int tg) {
+  const int nx = box.nc[0] > 0 ? box.nc[0] : 1, ny = box.nc[1] > 0 ? box.nc[1] : 1, nz = box.nc[2] > 0 ? box.nc[2] : 1;
+  const int cx = c % nx, cy = (c / nx) % ny;
+  const R clx = box.L[0] / (R)nx, cly = box.L[1] / (R)ny;
   int b = (int)((x.x - (R)cx * clx) * ((R)NSUB / clx));
   b = b < 0 ? 0 : (b > NSUB - 1 ? NSUB - 1 : b);
-  return (b << 27) | tg;     // tags < 2^27 (chem_set_particles)
+  const int hy = (x.y - (R)cy * cly) * (R)2 >= cly ? 1 : 0;
+  // z: the half is taken from the fractional cell coordinate (slab mode shifts the layer index, not the split)
+  const R zc = x.z * box.cell_inv[2];
+  const int hz = (zc - floor_r(zc)) >= (R)0.5 ? 1 : 0;
+  (void)nz;
+  return (b << 29) | (hy << 28) | (hz << 27) | tg;     // tags < 2^27 (chem_set_particles)
 }
 template <typename R>
 __device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start, const int* perm, const Vec4<R>* x4, const Vec4<R>* v4,
@@ -429,11 +439,11 @@ __device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start
       const int cc = c0 + half;
       int pi = 0, tg = 0, key = 0x7fffffff;
       Vec4<R> xp = mk4<R>(0, 0, 0, 0);
-      if (hl < cnt) { pi = perm[s + hl]; tg = tag[pi]; xp = x4[pi]; key = sort_key<R>(xp, cc % nx, box, tg); }
+      if (hl < cnt) { pi = perm[s + hl]; tg = tag[pi]; xp = x4[pi]; key = sort_key<R>(xp, cc, box, tg); }
       int rank = 0;
       for (int k = 0; k < cmax; ++k) { const int tk = __shfl(key, k, 32); rank += (k < cnt && tk < key) ? 1 : 0; }
       // members in front of slice 1, 2, 3 (per half-wave)
-      const int bin = key >> 27;
+      const int bin = key >> 29;
       unsigned int packed = 0;
 #pragma unroll
       for (int b = 1; b < NSUB; ++b) {
@@ -452,10 +462,10 @@ __device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start
       if (cnt <= 64) {
         int pi = 0, tg = 0, key = 0x7fffffff;
         Vec4<R> xp = mk4<R>(0, 0, 0, 0);
-        if (l < cnt) { pi = perm[s + l]; tg = tag[pi]; xp = x4[pi]; key = sort_key<R>(xp, cc % nx, box, tg); }
+        if (l < cnt) { pi = perm[s + l]; tg = tag[pi]; xp = x4[pi]; key = sort_key<R>(xp, cc, box, tg); }
         int rank = 0;
         for (int k = 0; k < cnt; ++k) { const int tk = __shfl(key, k); rank += (tk < key) ? 1 : 0; }
-        const int bin = key >> 27;
+        const int bin = key >> 29;
         unsigned int packed = 0;
 #pragma unroll
         for (int b = 1; b < NSUB; ++b) packed |= (unsigned int)__popcll(__ballot(l < cnt && bin < b)) << (8 * (b - 1));
@@ -1531,6 +1541,19 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
       double ff = 0;
       if (bp.kind == CHEM_POT_HARMONIC) { const double dr = r - p[1]; u = p[0] * dr * dr; ff = -2.0 * p[0] * dr / r; }
       else if (bp.kind == CHEM_POT_FENE) { const double dr = r - p[1], q = dr / p[2], den = 1.0 - q * q; u = -0.5 * p[0] * p[2] * p[2] * log(den); ff = -p[0] * dr / den / r; }
+      else if (bp.kind == CHEM_POT_FENE_LJ) {   // FENELennardJones(K, r0, rMax, sigma, epsilon)
+        const double dr = r - p[1], q = dr / p[2], den = 1.0 - q * q;
+        const double s2 = p[3] * p[3] / (r * r), s6 = s2 * s2 * s2;
+        u = -0.5 * p[0] * p[2] * p[2] * log(den) + 4.0 * p[4] * (s6 * s6 - s6);
+        ff = -p[0] * dr / den / r + 24.0 * p[4] * (2.0 * s6 * s6 - s6) / (r * r);
+      }
+      else if (bp.kind == CHEM_POT_LJ_BOND) {   // FixedPairListLennardJones(epsilon, sigma, cutoff): 1-4 pairs
+        if (r <= p[2]) {
+          const double s2 = p[1] * p[1] / (r * r), s6 = s2 * s2 * s2;
+          u = 4.0 * p[0] * (s6 * s6 - s6);
+          ff = 24.0 * p[0] * (2.0 * s6 * s6 - s6) / (r * r);
+        }
+      }
       else if (bp.kind == CHEM_POT_TABULATED) {   // Tabulated(itype=1): linear interpolation of e(r), f(r); end rows beyond the grid
         const double4 ti = bt.info[(int)p[0]];
         const double2* row = bt.rows + (size_t)ti.x;
@@ -1587,6 +1610,11 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
         double pw = 1.0, dsum = 0;
         for (int k = 0; k < 6; ++k) { u += p[k] * pw; if (k < 5) dsum += (k + 1) * p[k + 1] * pw; pw *= cp; }
         dU = -sp * dsum;
+      }
+      else if (bp.kind == CHEM_POT_DIH_HARMONIC) {   // DihedralHarmonic(K, phi0): U = K/2 (phi - phi0)^2, difference wrapped
+        double d = phi - p[1];
+        d -= 2.0 * M_PI * rint(d / (2.0 * M_PI));
+        u = 0.5 * p[0] * d * d; dU = p[0] * d;
       }
       else if (bp.kind == CHEM_POT_DIH_TABULATED) {   // TabulatedDihedral(itype=1): U(phi), -dU/dphi on a uniform grid over [-pi, pi]
         const double4 ti = bt.info[(int)p[0]];

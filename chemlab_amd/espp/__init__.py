@@ -352,6 +352,33 @@ class _FENE(_Pot):
         return [self.K, self.r0, self.rMax]
 
 
+class _FENELennardJones(_Pot):
+    """interaction.FENELennardJones(K, r0, rMax, sigma, epsilon) (bond func 9, gromacs_topology.py:935-942)."""
+    kind = "FENE_LJ"
+
+    def __init__(self, K=1.0, r0=0.0, rMax=1.0, sigma=1.0, epsilon=1.0, cutoff=None, shift=0.0):
+        self.K, self.r0, self.rMax, self.sigma, self.epsilon = K, r0, rMax, sigma, epsilon
+
+    def params(self):
+        return [self.K, self.r0, self.rMax, self.sigma, self.epsilon]
+
+
+class _LJBond(_Pot):
+    """LennardJones as the potential of a FixedPairListLennardJones (1-4 pairs, gromacs_topology.py:1314-1411)."""
+    kind = "LJ_BOND"
+
+
+class _DihedralHarmonic(_Pot):
+    """interaction.DihedralHarmonic(K, phi0) (dihedral func 12, gromacs_topology.py:1199-1202)."""
+    kind = "DIH_HARMONIC"
+
+    def __init__(self, K=0.0, phi0=0.0):
+        self.K, self.phi0 = K, phi0
+
+    def params(self):
+        return [self.K, self.phi0]
+
+
 class _AngularHarmonic(_Pot):
     kind = "ANG_HARMONIC"
 
@@ -434,6 +461,8 @@ class _FixedListInteraction(object):
             if id(eng) not in cache:
                 cache[id(eng)] = eng.table_create(pot.r0, pot.dr, pot.e, pot.f)
             return kind, [float(cache[id(eng)])]
+        if isinstance(pot, _LennardJones):      # FixedPairList[Types]LennardJones: 1-4 pairs
+            return "LJ_BOND", [pot.epsilon, pot.sigma, pot.cutoff if pot.cutoff is not None else 1e30]
         return pot.kind, pot.params()
 
     def __init__(self, system, flist, potential=None):
@@ -487,8 +516,12 @@ interaction = _ns(
     FixedTripleListTypesAngularHarmonic=_FixedListTypesInteraction, FixedTripleListTypesCosine=_FixedListTypesInteraction,
     FixedQuadrupleListDihedralHarmonicNCos=_FixedListInteraction, FixedQuadrupleListDihedralRB=_FixedListInteraction,
     FixedQuadrupleListTypesDihedralHarmonicNCos=_FixedListTypesInteraction, FixedQuadrupleListTypesDihedralRB=_FixedListTypesInteraction,
+    FENELennardJones=_FENELennardJones, DihedralHarmonic=_DihedralHarmonic,
+    FixedPairListFENELennardJones=_FixedListInteraction, FixedPairListTypesFENELennardJones=_FixedListTypesInteraction,
+    FixedPairListLennardJones=_FixedListInteraction, FixedPairListTypesLennardJones=_FixedListTypesInteraction,
+    FixedQuadrupleListDihedralHarmonic=_FixedListInteraction, FixedQuadrupleListTypesDihedralHarmonic=_FixedListTypesInteraction,
     # out of scope
-    FENELennardJones=_unsupported("interaction.FENELennardJones"), CoulombTruncated=_unsupported("interaction.CoulombTruncated"),
+    CoulombTruncated=_unsupported("interaction.CoulombTruncated"),
     VerletListCoulombTruncated=_unsupported("interaction.VerletListCoulombTruncated"),
     TabulatedAngular=_TabulatedAngular, TabulatedDihedral=_TabulatedDihedral,
     FixedQuadrupleListTabulatedDihedral=_FixedListInteraction, FixedQuadrupleListTypesTabulatedDihedral=_FixedListTypesInteraction,
@@ -767,10 +800,21 @@ class _ChemicalReaction(object):
         return []
 
     def save_reaction_counters(self, filename):
+        """events per reaction index (start_simulation.py:1028)"""
         ev = self.system.engine.get_events()
         with open(filename, "w") as f:
             for r in range(len(self._reactions)):
                 f.write("%d %d\n" % (r, int((ev["reaction"] == r).sum())))
+
+    def save_intra_inter_counter(self, filename):
+        """events between particles of the same / of different bonded clusters at the time of the event, per reaction
+        (start_simulation.py:1034); needs engine option count_intra_inter (the driver sets it)."""
+        ev = self.system.engine.get_events()
+        with open(filename, "w") as f:
+            f.write("# reaction intra inter\n")
+            for r in range(len(self._reactions)):
+                m = ev["reaction"] == r
+                f.write("%d %d %d\n" % (r, int((ev["pad"][m] == 1).sum()), int((ev["pad"][m] == 0).sum())))
 
 
 class _TopologyManager(object):
@@ -780,11 +824,39 @@ class _TopologyManager(object):
 
     def __init__(self, system):
         self.system = system
+        self._fpls = []
 
     def observe_tuple(self, fpl):
+        if getattr(fpl, "arity", 2) == 2 and fpl not in self._fpls:
+            self._fpls.append(fpl)
+
+    def observe_triple(self, ftl):
         pass
 
-    observe_triple = observe_quadruple = observe_tuple
+    observe_quadruple = observe_triple
+
+    # end-of-run dumps (start_simulation.py:1004-1006); layout: chemlab/outputs.py write_topology_dumps
+    def _dump(self, filename, suffix):
+        from ..chemlab import outputs
+        import os, shutil, tempfile
+        tmp = tempfile.mkdtemp()
+        try:
+            outputs.write_topology_dumps(os.path.join(tmp, "x"), self.system, self._fpls)
+            d = os.path.dirname(filename)
+            if d and not os.path.isdir(d):
+                os.makedirs(d)
+            shutil.move(os.path.join(tmp, "x" + suffix), filename)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+    def save_topology(self, filename):
+        self._dump(filename, "_topology.dat")
+
+    def save_res_topology(self, filename):
+        self._dump(filename, "_res_topology.dat")
+
+    def save_residues(self, filename):
+        self._dump(filename, "_residue_list.dat")
 
     def register_tuple(self, fpl, t1, t2):
         pass   # bonds never spawn from other bonds
@@ -997,4 +1069,26 @@ def _gaussian_velocities(T, n, masses, kb=1.0, seed=0):
 tools = _ns(decomp=_ns(nodeGrid=_node_grid, cellGrid=_cell_grid, tuneSkin=_unsupported("tools.decomp.tuneSkin")),
             velocities=_ns(gaussian=_gaussian_velocities),
             analyse=_ns(final_info=lambda *a, **k: None))
-io = _ns(DumpH5MD=_unsupported("io.DumpH5MD"), DumpTopology=_unsupported("io.DumpTopology"), DumpGRO=_unsupported("io.DumpGRO"))
+class _DumpGRO(object):
+    """io.DumpGRO(system, integrator, filename, unfolded=False, append=False): every particle, generic names
+    (start_simulation.py:1014-1016)."""
+
+    def __init__(self, system, integrator, filename="out.gro", unfolded=False, append=False, **kw):
+        self.system, self.filename, self.unfolded, self.append = system, filename, unfolded, append
+
+    def dump(self):
+        e = self.system.engine
+        ids, pos = e.get_state("ID"), e.get_state("POS_UNFOLDED" if self.unfolded else "POS")
+        vel, types, res = e.get_state("VEL"), e.get_state("TYPE"), e.get_state("RESID")
+        box = list(self.system.bc.boxL)
+        with open(self.filename, "a" if self.append else "w") as f:
+            f.write("system size %d\n%d\n" % (len(ids), len(ids)))
+            for k in range(len(ids)):
+                f.write("%5d%-5s%5s%5d%8.3f%8.3f%8.3f%8.4f%8.4f%8.4f\n" % (int(res[k]) % 100000, "T%d" % types[k], "T%d" % types[k], int(ids[k]) % 100000,
+                                                                            pos[k, 0], pos[k, 1], pos[k, 2], vel[k, 0], vel[k, 1], vel[k, 2]))
+            f.write("%f %f %f\n" % tuple(box))
+
+    perform_action = dump
+
+
+io = _ns(DumpH5MD=_unsupported("io.DumpH5MD (h5py is not available in this image)"), DumpTopology=_unsupported("io.DumpTopology (H5MD)"), DumpGRO=_DumpGRO)

@@ -6,17 +6,19 @@ configurations: same `@params` CLI, same cadence integers, same
     python -m chemlab_amd.start_simulation @params
 
 Reference: /root/reference/src/start_simulation.py -- cadence :100-103,265-270,645-673; set-up order
-:122-212; thermostat :329-354; main loop :728-796; benchmark row :997-998.  Output files beyond the
-energy CSV, the exclusion list and benchmark.csv (H5MD, topology dumps, .gro) are out of scope (f-3).
+:122-212; hooks.py discovery :214-228; maximum-conversion stop :280-287,759-777 (tools.py:102-180);
+thermostat :329-354; main loop :728-796; text outputs :738-744,800-1036 (chemlab/outputs.py);
+benchmark row :997-998.  H5MD trajectories (io.DumpH5MD / DumpTopology) need h5py, absent from this image.
 """
 import math
 import os
+import re
 import shutil
 import sys
 import time
 
 from . import espp as espressopp
-from .chemlab import app_args, files_io, gromacs_topology, reaction_parser, reaction_setup
+from .chemlab import app_args, files_io, gromacs_topology, outputs, reaction_parser, reaction_setup
 
 
 def cadence(args, cr_interval=None):
@@ -42,6 +44,99 @@ def cadence(args, cr_interval=None):
     energy_collect = min(cr_interval, args.energy_collect) if cr_interval else args.energy_collect
     return dict(integrator_step=integrator_step, sim_step=sim_step, k_enable_reactions=k_enable, k_stop_reactions=k_stop,
                 k_trj_collect=k_trj_collect, k_trj_flush=k_trj_flush, topol_collect=topol_collect, energy_collect=energy_collect)
+
+
+def load_hooks(path="hooks.py"):
+    """hooks.py in the working directory (start_simulation.py:214-228): a python file defining any of
+    hook_init_reaction, hook_postsetup_reaction, hook_at_step, hook_before_sim, hook_end.  `import espressopp`
+    inside it resolves to this package's shim."""
+    if not os.path.exists(path):
+        return {}
+    sys.modules.setdefault("espressopp", espressopp)
+    ns = {"__name__": "hooks", "espressopp": espressopp}
+    with open(path) as f:
+        exec(compile(f.read(), path, "exec"), ns)
+    return {k: ns[k] for k in ("hook_init_reaction", "hook_postsetup_reaction", "hook_at_step", "hook_before_sim", "hook_end") if k in ns}
+
+
+def get_maximum_conversion(args, system, chem_fpls, gt):
+    """--maximum_conversion "<what>:<max>:<total>,..." -> [(observable, stop value)] (tools.py:102-180):
+    `T1-T2` -> number of reaction bonds between those types >= max; `T(s)+U(t)` / `T` / `T(s)` -> fraction of the
+    `total` particles that have that type (and state) >= max/total."""
+    out = []
+    re_ts = re.compile(r"(?P<type>[A-Za-z0-9-]+)\(?(?P<state>\d?)\)?")
+    for o in args.maximum_conversion.split(","):
+        sym, max_number, tot_number = o.split(":")
+        max_number, tot_number = int(max_number), int(tot_number)
+        if "-" in sym:
+            for _, fpl, _ in chem_fpls:
+                out.append((espressopp.analysis.NFixedPairListEntries(system, fpl), max_number))
+                break
+        elif "+" in sym:
+            parts = []
+            for ts in sym.split("+"):
+                m = re_ts.match(ts).groupdict()
+                parts.append(espressopp.analysis.ChemicalConversionTypeState(system, gt.used_atomsym_atomtype[m["type"]],
+                                                                              int(m["state"]) if m["state"] else None, tot_number))
+            class _Sum(object):
+                def compute(self_inner):
+                    return sum(p.compute() for p in parts)
+            out.append((_Sum(), float(max_number) / tot_number))
+        else:
+            m = re_ts.match(sym).groupdict()
+            tid = gt.used_atomsym_atomtype[m["type"]]
+            obs = (espressopp.analysis.ChemicalConversionTypeState(system, tid, int(m["state"]), tot_number) if m["state"]
+                   else espressopp.analysis.ChemicalConversion(system, tid, tot_number))
+            out.append((obs, float(max_number) / tot_number))
+    return out
+
+
+def _conf_positions(system, conf, unfolded):
+    eng = system.engine
+    ids = eng.get_state("ID").tolist()
+    pos = eng.get_state("POS_UNFOLDED" if unfolded else "POS")
+    vel = eng.get_state("VEL")
+    return ({pid: pos[k] for k, pid in enumerate(ids) if pid in conf.atoms},
+            {pid: vel[k] for k, pid in enumerate(ids) if pid in conf.atoms})
+
+
+def write_final_outputs(args, system, gt, conf, bonded, angles, dihedrals, chem_fpls, topology_manager, ar, reaction_index):
+    """Everything start_simulation.py:836-1036 writes after the loop that does not need HDF5."""
+    prefix = "%s_%s" % (args.output_prefix, args.rng_seed)
+    valid = [gt.atomsym_atomtype[x] for x in args.table_groups.split(",")] if args.table_groups else None
+    atoms = outputs.output_atoms(system, gt, valid)
+
+    def split(groups):
+        static, dynamic = [], []
+        for name, (fl, inter) in groups.items():
+            if name.endswith("_dynamic"):
+                dynamic.append(fl)
+            else:
+                static.append((fl, inter.params))
+        return static, dynamic
+    b_static, b_dyn = split(bonded)
+    a_static, a_dyn = split(angles)
+    d_static, d_dyn = split(dihedrals)
+    brows = outputs.tuple_rows("bonds", b_static, b_dyn, [f for _, f, _ in chem_fpls], atoms, gt)
+    arows = outputs.tuple_rows("angles", a_static, a_dyn, [], atoms, gt)
+    drows = outputs.tuple_rows("dihedrals", d_static, d_dyn, [], atoms, gt)
+    outputs.write_rows(prefix + "_bonds.dat", brows)
+    outputs.write_rows(prefix + "_angles.dat", arows)
+    outputs.write_rows(prefix + "_dihedrals.dat", drows)
+    outputs.write_output_topology(prefix + "_output_topol.top", gt, atoms, brows, arows, drows)
+    topology_manager.save_topology(prefix + "_topology.dat")
+    topology_manager.save_res_topology(prefix + "_res_topology.dat")
+    topology_manager.save_residues(prefix + "_residue_list.dat")
+    pos, _ = _conf_positions(system, conf, unfolded=False)
+    outputs.write_gro(prefix + "_confout.gro", conf, pos, conf.box)
+    espressopp.io.DumpGRO(system, system.integrator, filename=prefix + "_whole_confout.gro").dump()
+    if ar is not None:
+        ar.save_reaction_counters(prefix + "_reaction_counters")
+        with open(prefix + "_reaction_counters", "a") as f:
+            f.write("\n\nReaction index\n")
+            for ridx in sorted(reaction_index):
+                f.write("%s %s\n" % (ridx, reaction_index[ridx]))
+        ar.save_intra_inter_counter(prefix + "_intra_inter_counters")
 
 
 def main(argv=None, hooks=None, quiet=False):
@@ -94,13 +189,19 @@ def main(argv=None, hooks=None, quiet=False):
     log("Bonds: %d\nAngles: %d\nDihedrals: %d" % (len(gt.bonds), len(gt.angles), len(gt.dihedrals)))
     topology_manager = espressopp.integrator.TopologyManager(system)
     system.topology_manager = topology_manager
-    hooks = hooks or {}
+    file_hooks = load_hooks()                     # hooks.py of the working directory; explicit `hooks` win
+    if file_hooks:
+        log("Found hooks.py")
+    hooks = dict(file_hooks, **(hooks or {}))
     ar, chem_fpls, cr_interval, dynamic_types = None, [], None, set()
+    reaction_index = {}
     if args.reactions is not None and os.path.exists(args.reactions):
         rc = reaction_parser.parse_config(args.reactions)
         sc = reaction_setup.SetupReactions(espressopp, system, verletlist, gt, topology_manager, rc, args)
         ar, chem_fpls = sc.setup_reactions()
         dynamic_types = sc.dynamic_types
+        reaction_index = {k: cr["equation"] for k, cr in enumerate(c for g in rc["reactions"].values() for c in g["reaction_list"])}
+        system.engine.set_option("count_intra_inter", 1)   # ar.save_intra_inter_counter at the end of the run
         shutil.copyfile(args.reactions, "%s_%s_%s" % (args.output_prefix, rng_seed, os.path.basename(args.reactions)))
         cr_interval = rc["general"]["interval"]
         cad = cadence(args, cr_interval)
@@ -112,8 +213,9 @@ def main(argv=None, hooks=None, quiet=False):
                                                       table_dir=os.path.dirname(os.path.abspath(args.top)))
     angles = gromacs_topology.set_angle_interactions(espressopp, system, gt, dynamic_types,
                                                      table_dir=os.path.dirname(os.path.abspath(args.top)))
-    if gt.dihedrals:
-        raise NotImplementedError("[ dihedrals ] from topology files: lowest priority in SURVEY.md 8 (a8); use the C ABI directly")
+    dihedrals = gromacs_topology.set_dihedral_interactions(espressopp, system, gt, dynamic_types,
+                                                           table_dir=os.path.dirname(os.path.abspath(args.top)))
+    pairs14 = gromacs_topology.set_pair_interactions(espressopp, system, gt, lj_cutoff, dynamic_types)   # start_simulation.py:308-309
     if args.max_force > -1:                               # start_simulation.py:320-324, before the thermostat
         integrator.addExtension(espressopp.integrator.CapForce(system, args.max_force))
         log("Cap force to %s" % args.max_force)
@@ -149,6 +251,11 @@ def main(argv=None, hooks=None, quiet=False):
         dynamic_exclusion_list.observe_triple(ftl)
         for types_ in inter._typed:
             topology_manager.register_triplet(ftl, *types_)
+    if "dihedral_dynamic" in dihedrals:                   # start_simulation.py:428-441
+        fql, inter = dihedrals["dihedral_dynamic"]
+        dynamic_exclusion_list.observe_quadruple(fql)
+        for types_ in inter._typed:
+            topology_manager.register_quadruplet(fql, *types_)
     topology_manager.initialize_topology()
     integrator.addExtension(topology_manager)
     # observables (start_simulation.py:447-569)
@@ -162,8 +269,14 @@ def main(argv=None, hooks=None, quiet=False):
         mon.add_observable("count_%d" % i, espressopp.analysis.NFixedPairListEntries(system, fpl))
     integrator.addExtension(espressopp.integrator.ExtAnalyze(mon, cad["energy_collect"]))
     espressopp.analysis.CMVelocity(system).reset()
+    maximum_conversion, eq_run = [], 0                    # start_simulation.py:280-287
+    if args.maximum_conversion and ar is not None:
+        maximum_conversion = get_maximum_conversion(args, system, chem_fpls, gt)
+        if args.eq_steps > 0:
+            eq_run = int(args.eq_steps / cad["sim_step"])
     # main loop (start_simulation.py:728-796)
     reactions_enabled = False
+    stop_simulation = False
     total_time = time.time()
     integrator_loop = 0.0
     if "hook_before_sim" in hooks:
@@ -174,23 +287,41 @@ def main(argv=None, hooks=None, quiet=False):
             log("Enabling chemical reactions")
             integrator.addExtension(ar)
             reactions_enabled = True
+            pos, vel = _conf_positions(system, conf, unfolded=True)      # start_simulation.py:741-745
+            outputs.write_gro("%s_%s_before_reaction_confout.gro" % (args.output_prefix, args.rng_seed), conf, pos, conf.box, velocities=vel)
             if "hook_init_reaction" in hooks and not hooks["hook_init_reaction"](system, integrator, ar, gt, args):
                 raise RuntimeError("hook_init_reaction return False")
-        if reactions_enabled and cad["k_stop_reactions"] == k:
-            ar.disconnect()
+        if reactions_enabled:
+            if not stop_simulation:                        # start_simulation.py:759-770
+                for obs, stop_value in maximum_conversion:
+                    val = obs.compute()
+                    if val >= stop_value:
+                        log("Reaches %s of the conversion => Stop simulation" % val)
+                        stop_simulation = True
+            if stop_simulation:
+                if eq_run == 0:
+                    break
+                eq_run -= 1
+            if cad["k_stop_reactions"] == k or stop_simulation:
+                ar.disconnect()
         t0 = time.time()
         integrator.run(cad["integrator_step"])
         integrator_loop += time.time() - t0
         if "hook_at_step" in hooks:
             hooks["hook_at_step"](system, integrator, ar, gt, args, k * cad["integrator_step"])
     total_time = time.time() - total_time
+    if "hook_end" in hooks:
+        hooks["hook_end"](system, integrator, ar, gt, args)
+    mon.info() if not quiet else None
+    write_final_outputs(args, system, gt, conf, bonded, angles, dihedrals, chem_fpls, topology_manager, ar, reaction_index)
     npart = espressopp.analysis.NPart(system).compute()
     with open("%s_%s_benchmark.csv" % (args.output_prefix, rng_seed), "a+") as f:
         f.write("%d %d %s %s\n" % (1, npart, total_time, integrator_loop))
     log("finished: %d steps, integratorLoop %.3f s, %.1f steps/s" % (cad["sim_step"] * cad["integrator_step"], integrator_loop,
                                                                        cad["sim_step"] * cad["integrator_step"] / max(integrator_loop, 1e-12)))
     return dict(system=system, integrator=integrator, gt=gt, ar=ar, chem_fpls=chem_fpls, cadence=cad, args=args,
-                total_time=total_time, integrator_loop=integrator_loop, bonded=bonded, angles=angles, monitor=mon)
+                total_time=total_time, integrator_loop=integrator_loop, bonded=bonded, angles=angles, dihedrals=dihedrals, monitor=mon,
+                stopped_by_conversion=stop_simulation)
 
 
 if __name__ == "__main__":

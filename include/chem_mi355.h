@@ -54,11 +54,17 @@ extern "C" {
 #define CHEM_POT_HARMONIC      1
 #define CHEM_POT_FENE          2
 #define CHEM_POT_TABULATED     3   /* bonds: params = { table handle } from chem_table_create */
+#define CHEM_POT_FENE_LJ       4   /* bonds func 9, FENELennardJones(K, r0, rMax, sigma, epsilon): FENE + 4 eps ((s/r)^12 - (s/r)^6),
+                                      doc/topology.rst:68-75, gromacs_topology.py:935-942 */
+#define CHEM_POT_LJ_BOND       5   /* 1-4 pairs, FixedPairListLennardJones(epsilon, sigma, cutoff): plain LJ inside the cutoff,
+                                      gromacs_topology.py:1314-1411 */
 #define CHEM_POT_ANG_HARMONIC 10
 #define CHEM_POT_ANG_COSINE   11
 #define CHEM_POT_ANG_TABULATED 12  /* angles func 8: params = { table handle }, grid in radians, f = -dU/dtheta */
 #define CHEM_POT_DIH_NCOS     20
 #define CHEM_POT_DIH_RB       21
+#define CHEM_POT_DIH_HARMONIC  23  /* dihedrals func 12, DihedralHarmonic(K, phi0): U = K/2 (phi - phi0)^2, difference wrapped to
+                                      (-pi, pi], doc/topology.rst:120-128, gromacs_topology.py:1199-1202 */
 #define CHEM_POT_DIH_TABULATED 22  /* dihedrals func 8: params = { table handle }, grid in radians over [-pi, pi], f = -dU/dphi */
 #define CHEM_MAX_POT_PARAMS    6
 #define CHEM_MAX_LISTS        32
@@ -109,7 +115,7 @@ typedef struct chem_event {
   int64_t step;
   int64_t id_a, id_b;     /* particle taking role type_1 / type_2 */
   int32_t reaction;
-  int32_t pad;
+  int32_t pad;            /* with option "count_intra_inter": 1 = both particles were in one bonded cluster before the event */
   double  r2;             /* fp64 squared distance at decision time */
 } chem_event;
 

@@ -122,6 +122,7 @@ struct Orc {
   double cap_force = 0;
   int resc_kind = 0; double resc_kT = 0, resc_param = 0;   // Berendsen / Isokinetic (chem_thermostat_rescale), 3 = SVR (chem_thermostat_svr)
   uint64_t svr_seed = 0;
+  bool count_intra_inter = false;
   struct BTable { double r0, dr; std::vector<double> e, f; };
   std::vector<BTable> btables;   // chem_table_create registry (tabulated bonds)
   double e_lj = 0, e_tab = 0, virial = 0;
@@ -359,6 +360,17 @@ static void bonded_forces(Orc& o) {
           double dr = r - p[1], q = dr / p[2], den = 1.0 - q * q;
           u = -0.5 * p[0] * p[2] * p[2] * std::log(den);
           ff = -p[0] * dr / den / r;
+        } else if (l.kind == CHEM_POT_FENE_LJ) {   // FENELennardJones(K, r0, rMax, sigma, epsilon), doc/topology.rst:68-75
+          double dr = r - p[1], q = dr / p[2], den = 1.0 - q * q;
+          double s2 = p[3] * p[3] / (r * r), s6 = s2 * s2 * s2;
+          u = -0.5 * p[0] * p[2] * p[2] * std::log(den) + 4.0 * p[4] * (s6 * s6 - s6);
+          ff = -p[0] * dr / den / r + 24.0 * p[4] * (2.0 * s6 * s6 - s6) / (r * r);
+        } else if (l.kind == CHEM_POT_LJ_BOND) {   // FixedPairListLennardJones(epsilon, sigma, cutoff): 1-4 pairs
+          if (r <= p[2]) {
+            double s2 = p[1] * p[1] / (r * r), s6 = s2 * s2 * s2;
+            u = 4.0 * p[0] * (s6 * s6 - s6);
+            ff = 24.0 * p[0] * (2.0 * s6 * s6 - s6) / (r * r);
+          }
         } else if (l.kind == CHEM_POT_TABULATED) {   // Tabulated(itype=1): linear interpolation, gromacs_topology.py:919-925
           const Orc::BTable& tb = o.btables[(size_t)p[0]];
           const int64_t nrow = (int64_t)tb.e.size();
@@ -409,6 +421,10 @@ static void bonded_forces(Orc& o) {
           double psi = phi - M_PI, cp = std::cos(psi), sp = std::sin(psi), pw = 1.0, dsum = 0;
           for (int k = 0; k < 6; ++k) { u += p[k] * pw; if (k < 5) { dsum += (k + 1) * p[k + 1] * pw; } pw *= cp; }
           dU = -sp * dsum;
+        } else if (l.kind == CHEM_POT_DIH_HARMONIC) {   // DihedralHarmonic(K, phi0): U = K/2 (phi - phi0)^2, doc/topology.rst:120-128
+          double d = phi - p[1];
+          d -= 2.0 * M_PI * std::nearbyint(d / (2.0 * M_PI));
+          u = 0.5 * p[0] * d * d; dU = p[0] * d;
         } else if (l.kind == CHEM_POT_DIH_TABULATED) {   // TabulatedDihedral(itype=1): U(phi), -dU/dphi, gromacs_topology.py:1192-1198
           const Orc::BTable& tb = o.btables[(size_t)p[0]];
           const int64_t nrow = (int64_t)tb.e.size();
@@ -644,7 +660,7 @@ static void react(Orc& o) {
     o.state[q.a] += R.delta_1; o.state[q.b] += R.delta_2;
     if (R.new_type_1 >= 0 && R.new_type_1 != o.type[q.a]) { o.type[q.a] = R.new_type_1; o.mass[q.a] = R.new_mass_1; o.q[q.a] = R.new_q_1; }
     if (R.new_type_2 >= 0 && R.new_type_2 != o.type[q.b]) { o.type[q.b] = R.new_type_2; o.mass[q.b] = R.new_mass_2; o.q[q.b] = R.new_q_2; }
-    o.events.push_back({o.step, o.id[q.a], o.id[q.b], q.r, 0, q.d2});
+    o.events.push_back({o.step, o.id[q.a], o.id[q.b], q.r, o.count_intra_inter && o.mol_id[q.a] == o.mol_id[q.b] ? 1 : 0, q.d2});   // pad: intra-cluster flag (option count_intra_inter)
     if (!R.is_virtual) {
       int32_t t[2] = {q.a, q.b};
       if (list_insert(o.lists[R.bond_list], t)) newbonds.emplace_back(q.a, q.b);
@@ -890,6 +906,7 @@ int orc_topology_register(void* c, int arity, int list, const int32_t* types) {
 int orc_set_option(void* c, const char* name, double value) {
   Orc& o = O(c); std::string k = name ? name : "";
   if (k == "rebuild_criterion") { o.criterion = value != 0 ? 1 : 0; o.resort = true; return 0; }
+  if (k == "count_intra_inter") { o.count_intra_inter = value != 0; return 0; }
   if (k == "threads") {   // all-core CPU baseline (needs the -fopenmp build, otherwise stays scalar)
 #ifdef _OPENMP
     o.threads = value >= 1 ? (int)value : 1; o.par = true; o.resort = true; return 0;
