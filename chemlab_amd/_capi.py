@@ -131,6 +131,7 @@ PRODUCT_ONLY = {
     "comm_unique_id": (_i, [C.c_char_p]),
     "comm_init": (_i, [_P, _i, _i, C.POINTER(C.c_int), C.c_char_p]),
     "comm_init_local": (_i, [_P, _i, _i, _i]),
+    "comm_init_ipc": (_i, [_P, _i, _i, C.c_char_p]),
 }
 
 

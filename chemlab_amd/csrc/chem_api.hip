@@ -1901,6 +1901,63 @@ int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], 
 // In-process ranks (several contexts of one process, one host thread each) exchanging through a
 // shared hub: validates the multi-rank decomposition on a single GPU.  Same contract as
 // chem_comm_init, `hub_id` names the group.
+namespace chem {
+IpcTransport::IpcTransport(int nr, int rk, const char* shm_name) {
+  nranks = nr; rank = rk; name = shm_name ? shm_name : "";
+  if (nr > IpcShm::kMaxRanks || name.empty()) throw ChemError(CHEM_EINVAL, "ipc transport: 1..16 ranks and a segment name");
+  // rank 0 creates the segment, the others wait for it (the launcher hands every rank the same fresh name)
+  int fd = -1;
+  if (rk == 0) {
+    shm_unlink(name.c_str());
+    fd = shm_open(name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, sizeof(IpcShm)) != 0) throw ChemError(CHEM_ECOMM, "ipc transport: cannot create shared memory " + name);
+    owner = true;
+  } else {
+    const double t0 = now();
+    struct stat st;
+    while ((fd = shm_open(name.c_str(), O_RDWR, 0600)) < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(IpcShm)) {
+      if (fd >= 0) { close(fd); fd = -1; }
+      if (now() - t0 > 120.0) throw ChemError(CHEM_ECOMM, "ipc transport: shared memory " + name + " did not appear");
+      usleep(1000);
+    }
+  }
+  void* p = mmap(nullptr, sizeof(IpcShm), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) throw ChemError(CHEM_ECOMM, "ipc transport: mmap");
+  shm = (IpcShm*)p;
+  if (rk == 0) { shm->P = (unsigned)nr; shm->arrived = 0; shm->gen = 0; shm->attached = 0; __atomic_store_n(&shm->magic, 0xC4E31234u, __ATOMIC_RELEASE); }
+  else {
+    const double t0 = now();
+    while (__atomic_load_n(&shm->magic, __ATOMIC_ACQUIRE) != 0xC4E31234u) { if (now() - t0 > 120.0) throw ChemError(CHEM_ECOMM, "ipc transport: segment never initialised"); usleep(1000); }
+    if (shm->P != (unsigned)nr) throw ChemError(CHEM_ECOMM, "ipc transport: rank count mismatch");
+  }
+  __atomic_add_fetch(&shm->attached, 1u, __ATOMIC_ACQ_REL);
+  barrier();
+}
+IpcTransport::~IpcTransport() {
+  for (auto& kv : opened) (void)hipIpcCloseMemHandle(kv.second);
+  if (shm) {
+    const unsigned left = __atomic_sub_fetch(&shm->attached, 1u, __ATOMIC_ACQ_REL);
+    munmap(shm, sizeof(IpcShm));
+    if (owner || left == 0) shm_unlink(name.c_str());
+  }
+}
+}  // namespace chem
+
+/* One process per rank, several ranks per device allowed: the slab decomposition of chem_comm_init over hipIpc
+ * memory handles with a POSIX shared-memory rendezvous named `shm_name` (same fresh name on every rank). */
+int chem_comm_init_ipc(chem_ctx* ctx, int nranks, int rank, const char* shm_name) {
+  API_BEGIN
+  Ctx& c = CTX;
+  REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks && shm_name, CHEM_EINVAL, "comm_init_ipc: rank/nranks/name");
+  REQUIRE(!c.dd_on && c.particles_dirty, CHEM_ESTATE, "comm_init_ipc must precede the first run");
+  HIPCHK(hipSetDevice(c.device));
+  c.tr.reset(new IpcTransport(nranks, rank, shm_name));
+  c.dd_on = true; c.P = nranks; c.rk = rank; c.geom_dirty = true;
+  return 0;
+  API_END(ctx)
+}
+
 int chem_comm_init_local(chem_ctx* ctx, int nranks, int rank, int hub_id) {
   API_BEGIN
   Ctx& c = CTX;

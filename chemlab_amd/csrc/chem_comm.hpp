@@ -8,9 +8,18 @@
 //   RcclTransport : production, one rank per GPU.
 //   SelfTransport : one rank whose lower and upper z-neighbour are itself (device-to-device copies);
 //                   exercises the whole ghost/migration machinery on a single GPU.
+//   LocalTransport: several ranks as threads of one process (shared hub).
+//   IpcTransport  : one PROCESS per rank, buffers mapped through hipIpc handles, rendezvous in POSIX shared
+//                   memory: the real multi-process flow on a box with fewer GPUs than ranks.
 #pragma once
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
 
 #include <condition_variable>
 #include <cstring>
@@ -247,6 +256,123 @@ struct LocalTransport : Transport {
     }
     ck(hipStreamSynchronize(s));
     hub->barrier();
+  }
+};
+
+
+// ---- inter-process transport over hipIpc memory handles: one process per rank, ranks on the same or on
+// different devices of one node.  Same protocol as LocalTransport (post buffer, rendezvous, copy what the
+// neighbour posted, rendezvous), with the rendezvous in a POSIX shared-memory segment and the posted
+// buffers mapped through hipIpcOpenMemHandle (mappings cached per peer allocation).
+// Why it exists: RCCL refuses two ranks on one device, so on a one-GPU box this is the only way to run the
+// REAL multi-process flow (torchrun rendezvous, per-rank set-up, collective order, teardown) end to end;
+// production multi-GPU runs use RcclTransport.
+struct IpcShm {
+  static constexpr int kMaxRanks = 16;
+  struct Post { hipIpcMemHandle_t h[2]; unsigned long long off[2], bytes[2]; };
+  unsigned int magic, P;
+  volatile unsigned int arrived, gen;         // sense-reversing barrier (GCC atomics)
+  volatile unsigned int attached;
+  Post post[kMaxRanks];
+  double red[kMaxRanks][64];
+};
+
+struct IpcTransport : Transport {
+  IpcShm* shm = nullptr; std::string name; bool owner = false;
+  std::map<std::string, void*> opened;        // (rank, handle bytes) -> mapped base pointer
+  static void ck(hipError_t e, const char* what) { if (e != hipSuccess) throw ChemError(CHEM_ECOMM, std::string("ipc transport: ") + what + ": " + hipGetErrorString(e)); }
+  IpcTransport(int nr, int rk, const char* shm_name);
+  ~IpcTransport() override;
+  void barrier() {
+    const unsigned int g = __atomic_load_n(&shm->gen, __ATOMIC_ACQUIRE);
+    if (__atomic_add_fetch(&shm->arrived, 1u, __ATOMIC_ACQ_REL) == (unsigned)nranks) {
+      __atomic_store_n(&shm->arrived, 0u, __ATOMIC_RELAXED);
+      __atomic_add_fetch(&shm->gen, 1u, __ATOMIC_RELEASE);
+      return;
+    }
+    const double t0 = now();
+    while (__atomic_load_n(&shm->gen, __ATOMIC_ACQUIRE) == g) {
+      sched_yield();
+      if (now() - t0 > 120.0) throw ChemError(CHEM_ECOMM, "ipc transport: a rank did not reach the rendezvous within 120 s");
+    }
+  }
+  static double now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+  void fill(IpcShm::Post& p, int k, const void* ptr, size_t bytes) {
+    p.bytes[k] = bytes; p.off[k] = 0;
+    if (!bytes) return;
+    hipDeviceptr_t base = nullptr; size_t size = 0;
+    ck(hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr), "hipMemGetAddressRange");
+    ck(hipIpcGetMemHandle(&p.h[k], base), "hipIpcGetMemHandle");
+    p.off[k] = (unsigned long long)((const char*)ptr - (const char*)base);
+  }
+  const void* peer_ptr(int q, int k) {
+    const IpcShm::Post& p = shm->post[q];
+    if (q == rank) throw ChemError(CHEM_ECOMM, "ipc transport: internal (self peer)");
+    std::string key((const char*)&p.h[k], sizeof(hipIpcMemHandle_t));
+    key.push_back((char)q);
+    auto it = opened.find(key);
+    if (it == opened.end()) {
+      void* base = nullptr;
+      ck(hipIpcOpenMemHandle(&base, p.h[k], hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+      it = opened.emplace(key, base).first;
+    }
+    return (const char*)it->second + p.off[k];
+  }
+  void copy_from(int q, int k, void* dst, size_t bytes, const void* own_src, hipStream_t s) {
+    if (shm->post[q].bytes[k] != bytes) throw ChemError(CHEM_ECOMM, "ipc transport: message size mismatch");
+    if (!bytes) return;
+    const void* src = q == rank ? own_src : peer_ptr(q, k);
+    ck(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s), "copy");
+  }
+  void exchange(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes, void* from_lo,
+                size_t from_lo_bytes, int lower, int upper, hipStream_t s) override {
+    ck(hipStreamSynchronize(s), "sync");
+    fill(shm->post[rank], 0, dn, dn_bytes); fill(shm->post[rank], 1, up, up_bytes);
+    barrier();
+    copy_from(upper, 0, from_up, from_up_bytes, dn, s);    // what the upper neighbour sent down
+    copy_from(lower, 1, from_lo, from_lo_bytes, up, s);    // what the lower neighbour sent up
+    ck(hipStreamSynchronize(s), "sync");
+    barrier();
+  }
+  void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
+                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) override {
+    exchange(dn, dn_bytes, up, up_bytes, from_up, from_up_bytes, from_lo, from_lo_bytes, lower, upper, s);
+    double v = 0;
+    ck(hipMemcpyAsync(&v, my, sizeof(double), hipMemcpyDeviceToHost, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+    shm->red[rank][0] = v;
+    barrier();
+    double a[IpcShm::kMaxRanks];
+    for (int q = 0; q < nranks; ++q) a[q] = shm->red[q][0];
+    ck(hipMemcpyAsync(all, a, sizeof(double) * nranks, hipMemcpyHostToDevice, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+    barrier();
+  }
+  void allreduce(double* dev, size_t count, hipStream_t s, bool is_max) {
+    if (count > 64) throw ChemError(CHEM_ECOMM, "ipc transport: reduction of more than 64 values");
+    double v[64];
+    ck(hipMemcpyAsync(v, dev, count * sizeof(double), hipMemcpyDeviceToHost, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+    for (size_t k = 0; k < count; ++k) shm->red[rank][k] = v[k];
+    barrier();
+    for (size_t k = 0; k < count; ++k) {
+      double r = shm->red[0][k];
+      for (int q = 1; q < nranks; ++q) { const double o = shm->red[q][k]; r = is_max ? (o > r ? o : r) : r + o; }
+      v[k] = r;
+    }
+    ck(hipMemcpyAsync(dev, v, count * sizeof(double), hipMemcpyHostToDevice, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+    barrier();
+  }
+  void allreduce_max_f64(double* dev, size_t count, hipStream_t s) override { allreduce(dev, count, s, true); }
+  void allreduce_sum_f64(double* dev, size_t count, hipStream_t s) override { allreduce(dev, count, s, false); }
+  void allgather(const void* in, void* out, size_t bytes, hipStream_t s) override {
+    ck(hipStreamSynchronize(s), "sync");
+    fill(shm->post[rank], 0, in, bytes); shm->post[rank].bytes[1] = 0;
+    barrier();
+    for (int q = 0; q < nranks; ++q) {
+      void* dst = (char*)out + (size_t)q * bytes;
+      if (q == rank) { if (in != dst && bytes) ck(hipMemcpyAsync(dst, in, bytes, hipMemcpyDeviceToDevice, s), "copy"); }
+      else copy_from(q, 0, dst, bytes, nullptr, s);
+    }
+    ck(hipStreamSynchronize(s), "sync");
+    barrier();
   }
 };
 

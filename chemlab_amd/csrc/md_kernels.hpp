@@ -430,7 +430,6 @@ __device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start
   // occupancy is ~18 -- otherwise one cell per wave / the global-memory ranking for crowded cells.
   const int l = lane_id(), hl = l & 31, half = l >> 5;
   const int nw = gridDim.x * (blockDim.x >> 6);
-  const int nx = box.nc[0] > 0 ? box.nc[0] : 1;
   for (int c0 = 2 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); c0 < ncell; c0 += 2 * nw) {
     const int s0 = cell_start[c0], s1 = cell_start[c0 + 1], s2 = c0 + 1 < ncell ? cell_start[c0 + 2] : s1;
     const int cnt0 = s1 - s0, cnt1 = s2 - s1;

@@ -254,6 +254,10 @@ class Engine:
         grid = (C.c_int * 3)(1, 1, nranks)
         self._ck(self.api.comm_init(self.ctx, nranks, rank, grid, uid))
 
+    def comm_init_ipc(self, nranks, rank, shm_name):
+        """One process per rank over hipIpc handles (ranks may share a device); shm_name: same fresh name on all ranks."""
+        self._ck(self.api.comm_init_ipc(self.ctx, nranks, rank, shm_name.encode()))
+
     def comm_init_local(self, nranks, rank, hub_id):
         self._ck(self.api.comm_init_local(self.ctx, nranks, rank, hub_id))
 

@@ -69,13 +69,41 @@ def max_over_ranks(dist, value):
     return float(t[0])
 
 
+def pick_transport(world):
+    """'rccl' (one rank per GPU: production) or 'ipc' (hipIpc handles + shared-memory rendezvous: ranks may share a
+    device -- RCCL refuses that).  CHEM_TRANSPORT overrides; by default IPC is taken only when the node has fewer
+    GPUs than ranks (the one-GPU rehearsal of the multi-process flow)."""
+    forced = os.environ.get("CHEM_TRANSPORT")
+    if forced:
+        return forced
+    try:
+        import torch
+        ndev = torch.cuda.device_count()
+    except Exception:
+        ndev = world
+    return "rccl" if ndev >= world else "ipc"
+
+
 def make_engine(rank, local_rank, world, precision=32):
-    """Engine of this rank, joined to the decomposition (RCCL communicator over all ranks)."""
+    """Engine of this rank, joined to the decomposition (RCCL communicator over all ranks, or the IPC transport)."""
     from .engine import Engine, comm_unique_id
     dist = init_process_group()
-    eng = Engine(device=local_rank, precision=precision)
-    uid = broadcast_bytes(dist, comm_unique_id() if rank == 0 else None)
-    eng.comm_init(world, rank, uid)
+    transport = pick_transport(world)
+    device = local_rank
+    if transport == "ipc":
+        try:
+            import torch
+            device = local_rank % max(1, torch.cuda.device_count())
+        except Exception:
+            device = 0
+    eng = Engine(device=device, precision=precision)
+    if transport == "ipc":
+        name = broadcast_bytes(dist, ("/chem_ipc_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getpid())) if rank == 0 else None)
+        eng.comm_init_ipc(world, rank, name)
+    else:
+        uid = broadcast_bytes(dist, comm_unique_id() if rank == 0 else None)
+        eng.comm_init(world, rank, uid)
+    eng.transport = transport
     return eng, dist
 
 
@@ -90,7 +118,8 @@ def device_sync(eng, local_rank):
 
 
 def bench_main(a, spec, rank, local_rank, world):
-    """bench.py for N > 1: strong scaling of the same 1M-particle box over `world` slabs."""
+    """bench.py for N > 1: strong scaling of the same 1M-particle box over `world` slabs.  Same sequence as the
+    one-GPU leg: melt without reactions, enable them, warm up, barrier, EXACTLY K timed steps, barrier, max over ranks."""
     from . import workloads as W
     eng, dist = make_engine(rank, local_rank, world, a.precision)
     W.apply(spec, eng)
@@ -99,10 +128,15 @@ def bench_main(a, spec, rank, local_rank, world):
     for kv in getattr(a, "opt", []):
         k, v = kv.split("=")
         eng.set_option(k, float(v))
+    eng.reactions_enable(False)
+    eng.run(a.equil)
+    eng.reactions_enable(True)
     eng.run(a.warmup)
     device_sync(eng, local_rank)
+    ev0 = len(eng.get_events())
+    tm0 = eng.timers()
     if not getattr(a, "no_roofline", False):
-        eng.set_option("time_pair_kernel", 8)              # HIP events around every 8th force launch of the timed region
+        eng.set_option("time_pair_kernel", max(1, a.steps // 256))   # HIP events around the force launches of every N-th timed step
     dist.barrier()
     t0 = time.perf_counter()
     eng.run(a.steps)
@@ -111,26 +145,30 @@ def bench_main(a, spec, rank, local_rank, world):
     wall = max_over_ranks(dist, time.perf_counter() - t0)
     tm = eng.timers()
     eng.set_option("time_pair_kernel", 0)
-    nev = len(eng.get_events())
+    nev = len(eng.get_events()) - ev0
     if rank == 0:
         sps = a.steps / wall
         out = dict(metric="MD steps/sec, 1M-particle reactive LJ melt", value=sps, unit="steps/s", n_gpus=world,
                    steps=a.steps, warmup=a.warmup, ms_per_step=1e3 * wall / a.steps, higher_is_better=True,
                    scaling="strong", vs_baseline=None, dtype="f32" if a.precision == 32 else "f64", data="synthetic",
-                   config=dict(workload="C5 reactive LJ melt (chain_growth_catalytic shape): %d particles, rho*=%.4g, rc=2.5, skin=0.3, dt=0.005, Langevin gamma=5 T=0.5, 4 reactions every %d steps"
-                                        % (a.n, a.rho, a.interval),
-                               particles=a.n, reaction_interval=a.interval, reaction_events_total=nev,
-                               tau_per_day=sps * spec["dt"] * 86400,
-                               parallelism="spatial slab decomposition along z over %d GPUs, RCCL ghost-layer exchange" % world))
+                   config=dict(workload="C5 reactive LJ melt (chain_growth_catalytic shape): %d particles, rho*=%.4g, rc=2.5, skin=0.3, dt=0.005, Langevin gamma=5 T=0.5, "
+                                        "4 reactions every %d steps; melted for %d steps before the reactions start" % (a.n, a.rho, a.interval, a.equil),
+                               particles=a.n, reaction_interval=a.interval, equilibration_steps=a.equil,
+                               reaction_steps_timed=int(tm["reaction_steps"] - tm0["reaction_steps"]), reaction_events=int(nev),
+                               list_rebuilds_timed=int(tm["rebuilds"] - tm0["rebuilds"]),
+                               tau_per_day=sps * spec["dt"] * 86400, transport=eng.transport,
+                               parallelism="spatial slab decomposition along z over %d GPUs, ghost-layer exchange over %s"
+                                           % (world, "RCCL point-to-point (xGMI)" if eng.transport == "rccl" else "hipIpc peer copies")))
         if tm["pair_kernel_launches"] > 0:
             # per-GPU figure of rank 0: its slab's share of the force list against ONE GPU's HBM peak
             avg_s = 1e-3 * tm["pair_kernel_ms"] / tm["pair_kernel_launches"]
             n_loc = a.n / float(world)
             nb = tm["nlist_entries"] / n_loc
-            bpp = 36.0 + 4.0 * nb
+            bpp = 36.0 + 2.0 * nb      # 16-bit tile-local slots (restated as SURVEY 8d demands; int32 formula: 36 + 4 nb)
             out["roofline"] = dict(bound="hbm", kernel="k_pair_tiles (rank 0, its slab)", achieved=n_loc * bpp / avg_s / 1e9, peak=8000.0, unit="GB/s",
-                                   frac=n_loc * bpp / avg_s / 8.0e12, traffic=None, avg_launch_us=avg_s * 1e6, launches=tm["pair_kernel_launches"],
-                                   mean_neighbours=nb, algorithmic_bytes_per_particle=bpp)
+                                   frac=n_loc * bpp / avg_s / 8.0e12, traffic=None, traffic_source=None, avg_launch_us=avg_s * 1e6,
+                                   launches_sampled=tm["pair_kernel_launches"], mean_neighbours=nb, algorithmic_bytes_per_particle=bpp,
+                                   frac_survey_int32_formula=n_loc * (36.0 + 4.0 * nb) / avg_s / 8.0e12)
         print(json.dumps(out))
     dist.barrier()
     eng.close()

@@ -298,6 +298,10 @@ int chem_comm_init(chem_ctx* ctx, int nranks, int rank, const int node_grid[3], 
  * exchanging by device-to-device copies through a hub named `hub_id`: several domains on a single
  * GPU; used to validate the multi-rank path without a multi-GPU node. */
 int chem_comm_init_local(chem_ctx* ctx, int nranks, int rank, int hub_id);
+/* Same decomposition with one PROCESS per rank and the ghost/migration buffers mapped through hipIpc memory handles
+ * (rendezvous in the POSIX shared-memory segment `shm_name`, the same fresh name on every rank): ranks may share a
+ * device, which RCCL refuses -- the multi-process flow of `bench.py --gpus N` on a box with fewer than N GPUs. */
+int chem_comm_init_ipc(chem_ctx* ctx, int nranks, int rank, const char* shm_name);
 
 #ifdef __cplusplus
 }

@@ -908,3 +908,54 @@ def test_change_neighbours_property_matches_oracle(make_gpu, make_oracle):
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
     g.run(0); o.run(0)
     assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_bench_multi_process_over_ipc_on_one_gpu(tmp_path, nranks):
+    """The REAL multi-process flow of `bench.py --gpus N` (torchrun rendezvous, one process per rank, per-rank set-up,
+    collective order, teardown) on the one leased GPU: RCCL refuses several ranks on a device, the hipIpc transport
+    (chem_comm_init_ipc) does not.  The event count and the particle total must equal the single-domain run's."""
+    import json, socket, subprocess, sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", CHEM_TRANSPORT="ipc")
+    common = ["--steps", "40", "--warmup", "10", "--n", "64000", "--interval", "20", "--equil", "100", "--cpu-steps", "0", "--f64-steps", "0"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nranks)] + common
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == nranks and d["steps"] == 40 and d["value"] > 0 and d["config"]["transport"] == "ipc"
+    assert d["config"]["reaction_steps_timed"] == 2 and d["config"]["reaction_events"] > 0
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--precision", "32", "--no-roofline"] + common,
+                         capture_output=True, text=True, timeout=900, env=dict(os.environ), cwd=str(tmp_path))
+    assert one.returncode == 0, one.stderr[-3000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    # fp32 trajectories of different decompositions differ in the last bits (summation order), the chemistry of a
+    # melt this size over 2 reaction steps stays statistically the same: same order of magnitude of events
+    assert 0.5 < d["config"]["reaction_events"] / float(d1["config"]["reaction_events"]) < 2.0
+
+
+@pytest.mark.gpu
+def test_destroying_a_decomposed_context_with_work_in_flight(make_oracle):
+    """Round-1 abort (`Memory critical error ... Memory in use` at exit, host segfault inside chem_run): the decomposed
+    path's decision kernel writes its verdict into PINNED HOST words (hflag); a context destroyed while such a kernel was
+    still queued freed those words under it.  ~CtxT now drains the stream before hipHostFree.  This test destroys
+    dd_self contexts right after queueing steps, with no explicit sync, several times in a row."""
+    from chemlab_amd.engine import Engine
+    spec = W.reactive_melt(n=32000, seed=21, interval=7)
+    for k in range(6):
+        e = Engine(device=0, precision=32)
+        e.set_option("dd_self", 1)
+        W.apply(spec, e)
+        e.run(5 + 3 * k)          # returns with the last launches possibly still executing
+        e.close()                 # chem_destroy: no chem_device_sync before it
+    e = Engine(device=0, precision=32)      # the device is still healthy afterwards
+    W.apply(spec, e)
+    e.run(3)
+    assert np.isfinite(e.get_state("FORCE")).all()
+    e.close()

@@ -10,7 +10,7 @@ e = Engine(precision=32)
 W.apply(spec, e)
 for kv in sys.argv[2:]:
     k, v = kv.split('='); e.set_option(k, float(v))
-e.run(50)
+e.reactions_enable(False); e.run(int(__import__("os").environ.get("EQUIL", "50")))
 e.set_option("debug_stamps", 1)
 e.run(3)
 e.sync()
