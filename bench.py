@@ -37,7 +37,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2000)
     p.add_argument("--warmup", type=int, default=200)
-    p.add_argument("--n", type=int, default=1000000, help="particles (C5: 1,000,000 = 100^3 sc lattice)")
+    # (`--particles`, not `--n`: torch.distributed.run's own parser claims every `--n...` prefix as ambiguous)
+    p.add_argument("--particles", "--n", dest="n", type=int, default=1000000, help="particles (C5: 1,000,000 = 100^3 sc lattice)")
     p.add_argument("--rho", type=float, default=0.8)
     p.add_argument("--interval", type=int, default=500)
     p.add_argument("--equil", type=int, default=2000, help="untimed melting steps before reactions are enabled")

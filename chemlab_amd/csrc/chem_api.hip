@@ -146,7 +146,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int4> img4, img4o;
   DBuf<int> cell_cnt, cell_start, cell_of, slot_of, perm, cell_sub;
   // fused rebuild (single domain, tiles): segment scans + grid barrier state
-  DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot; DBuf<GridBar> gbar;
+  DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot, cell_n, bucket; int bcap = 0; DBuf<GridBar> gbar;
   DBuf<int> tile_cnt, tile_off;   // reaction scan on tiles: candidates per tile, their offsets
   DBuf<int4> bwork, bj; int nb_owner = 0; bool bwork_dirty = true;   // bonded work list (see dev_bonded_prep)
   int fused_grid = 0, fused_par = 0, seg_shift = 0, tseg_shift = 0; bool use_fused = false;
@@ -293,6 +293,11 @@ template <typename R> struct CtxT : Ctx {
     auto shift_for = [&](int nitem) { int sh = 0; while (((nitem + (1 << sh) - 1) >> sh) > g) ++sh; return sh; };
     seg_shift = shift_for(box.ncell); tseg_shift = shift_for(ntiles);
     cell_loc.alloc(box.ncell + 1); seg_tot.alloc(1024); tile_n.alloc(ntiles + 1); tile_loc.alloc(ntiles + 1); tseg_tot.alloc(1024);
+    // bucket rows of the binning pass: 64 members per cell = what one wave sorts (the LDS tiles already require a mean
+    // cell occupancy far below that); a fuller cell raises ctl->bucket_overflow and the unfused chain takes over
+    cell_n.alloc(box.ncell + 1);
+    bcap = 64;
+    bucket.alloc((size_t)box.ncell * bcap);
     if (!gbar.p) { gbar.alloc(1); HIPCHK(hipMemsetAsync(gbar.p, 0, sizeof(GridBar), stream)); }
     use_fused = true;
   }
@@ -304,7 +309,7 @@ template <typename R> struct CtxT : Ctx {
     a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
     a.cell_cnt = cell_cnt.p; a.cell_of = cell_of.p; a.slot_of = slot_of.p; a.cell_start = cell_start.p; a.cell_loc = cell_loc.p;
-    a.cell_sub = cell_sub.p; a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
+    a.cell_sub = cell_sub.p; a.cell_n = cell_n.p; a.bucket = bucket.p; a.bcap = bcap; a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
     a.desc = tdesc.p; a.excl_start = excl_start.p; a.excl_list = excl_list.p; a.nl16 = nl16.p; a.nnh = nnh.p; a.nlist = nlist.p; a.nn = nn.p;
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
     a.bstart = bstart.p; a.bent = bent.p; a.bwork = bwork.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
@@ -705,6 +710,14 @@ template <typename R> struct CtxT : Ctx {
       if (dd_on) agree_flags(h);
       if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
       if (h.barrier_timeout) throw ChemError(CHEM_ESTATE, "fused rebuild: grid barrier timed out (device shared with another job?); set option fused_rebuild=0");
+      if (h.bucket_overflow) {
+        // a cell more crowded than a bucket row: widen the rows up to what one wave sorts (64), beyond that this
+        // system needs the unfused chain (its crowded-cell path ranks through global memory)
+        set_ctl_field(&DevCtl::bucket_overflow, 0);
+        if (h.bucket_overflow <= 64 && bcap < 64) { bcap = 64; bucket.alloc((size_t)box.ncell * bcap); }
+        else { use_fused = false; if (g_trace) fprintf(stderr, "[chem trace] cell with %d particles: fused rebuild off\n", h.bucket_overflow); }
+        continue;
+      }
       if (h.stage_overflow) {
         // denser than the mean-occupancy estimate (clusters, chains): grow the staged-tile capacity while it
         // fits the LDS, then build again; beyond that the system is too crowded for tiles
@@ -843,6 +856,7 @@ template <typename R> struct CtxT : Ctx {
     if (h.skin_violation) throw ChemError(CHEM_ESTATE, "internal: neighbour list used past skin/2");
     if (h.excl_slot_error) throw ChemError(CHEM_ESTATE, "internal: list build could not locate an excluded partner in its cell");
     if (h.barrier_timeout) throw ChemError(CHEM_ESTATE, "fused rebuild: grid barrier timed out (device shared with another job?); set option fused_rebuild=0");
+    if (h.bucket_overflow) throw ChemError(CHEM_ENOSPC, "a cell filled up with " + std::to_string(h.bucket_overflow) + " particles during the run (fused rebuild bucket rows hold " + std::to_string(bcap) + "); set option fused_rebuild=0");
     if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
   }
 

@@ -61,6 +61,8 @@ struct DevCtl {
   double acc_pp[2];                   // fused rebuild: accumulated distance, double-buffered by launch parity
   int bwork_count;                    // particles in the bonded work list
   int excl_slot_error;                // list build: an excluded partner was not found in the cell computed from its position (internal)
+  int bucket_overflow;                // fused rebuild: a cell holds more particles than a bucket row (value = needed capacity)
+  int pad1;
 };
 
 template <typename R> struct Box {
@@ -243,9 +245,12 @@ __global__ void k_collect_ints(CollectArgs a, volatile int* host, int ticket) {
 // slab travel to the neighbour rank with their full state
 template <typename R> struct MigBuf { int* count; Vec4<R>* x; Vec4<R>* v; int4* img; int* tag; int cap; };
 
+// bucket != nullptr (fused rebuild): member `slot` of cell `cid` is recorded at bucket[cid * bcap + slot] right away
+// (fixed-capacity rows), so that the sort phase needs no separate placement pass; cell_of / slot_of are not written.
 template <typename R>
 __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R>* v4, const int* tag, int4* img4, const Box<R>& box,
-                                        int* cell_cnt, int* cell_of, int* slot_of, const MigBuf<R>& mdn, const MigBuf<R>& mup, DevCtl* ctl) {
+                                        int* cell_cnt, int* cell_of, int* slot_of, const MigBuf<R>& mdn, const MigBuf<R>& mup, DevCtl* ctl,
+                                        int* bucket = nullptr, int bcap = 0) {
   // the loop bound is wave-uniform (rounded up) because the slot assignment below uses cross-lane ops
   const int iend = i0 + n;
   for (int ib = i0 + blockIdx.x * blockDim.x; ib < iend; ib += gridDim.x * blockDim.x) {
@@ -286,7 +291,7 @@ __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R
         cell_of[i] = -1;
       } else {
         cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
-        cell_of[i] = cid;
+        if (!bucket) cell_of[i] = cid;
       }
     }
     // Slot inside the cell.  The arrays are still in the cell order of the previous rebuild, so
@@ -304,7 +309,12 @@ __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R
     int base = 0;
     if (head && cid >= 0) base = atomicAdd(&cell_cnt[cid], end - start);
     base = __shfl(base, start);
-    if (cid >= 0) slot_of[i] = base + (lane - start);
+    if (cid >= 0) {
+      const int slot = base + (lane - start);
+      if (!bucket) slot_of[i] = slot;
+      else if (slot < bcap) bucket[(size_t)cid * bcap + slot] = i;
+      else atomicMax(&ctl->bucket_overflow, slot + 1);
+    }
   }
 }
 
@@ -483,6 +493,63 @@ __device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start
           const int dst = s + rank;
           x4o[dst] = x4[pi]; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
         }
+      }
+    }
+  }
+}
+
+// Fused-rebuild variant: members come from the fixed-capacity bucket rows filled while binning, the cell's first
+// index is computed here (cell_loc + segment offset) and published as cell_start; <= 64 members per cell (bucket
+// capacity is checked at binning time).
+template <typename R>
+__device__ __forceinline__ void dev_sort_gather_bucket(int ncell, const int* cell_loc, const int* cell_n, const int* s_off, int seg_shift,
+                                                       const int* bucket, int bcap, int* cell_start, const Vec4<R>* x4, const Vec4<R>* v4,
+                                                       const int* tag, const int4* img4, Vec4<R>* x4o, Vec4<R>* v4o, int* tago, int4* img4o,
+                                                       const Box<R>& box, int* cell_sub) {
+  const int l = lane_id(), hl = l & 31, half = l >> 5;
+  const int nw = gridDim.x * (blockDim.x >> 6);
+  for (int c0 = 2 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); c0 < ncell; c0 += 2 * nw) {
+    const bool two = c0 + 1 < ncell;
+    const int cnt0 = cell_n[c0], cnt1 = two ? cell_n[c0 + 1] : 0;
+    const int s0 = cell_loc[c0] + s_off[c0 >> seg_shift], s1 = two ? cell_loc[c0 + 1] + s_off[(c0 + 1) >> seg_shift] : s0 + cnt0;
+    if (l == 0) { cell_start[c0] = s0; if (two) cell_start[c0 + 1] = s1; }
+    if (cnt0 <= 32 && cnt1 <= 32) {
+      const int s = half ? s1 : s0, cnt = half ? cnt1 : cnt0, cmax = cnt0 > cnt1 ? cnt0 : cnt1;
+      const int cc = c0 + half;
+      int pi = 0, tg = 0, key = 0x7fffffff;
+      Vec4<R> xp = mk4<R>(0, 0, 0, 0);
+      if (hl < cnt) { pi = bucket[(size_t)cc * bcap + hl]; tg = tag[pi]; xp = x4[pi]; key = sort_key<R>(xp, cc, box, tg); }
+      int rank = 0;
+      for (int k = 0; k < cmax; ++k) { const int tk = __shfl(key, k, 32); rank += (k < cnt && tk < key) ? 1 : 0; }
+      const int bin = key >> 29;
+      unsigned int packed = 0;
+#pragma unroll
+      for (int b = 1; b < NSUB; ++b) {
+        const unsigned long long m = __ballot(hl < cnt && bin < b);
+        packed |= (unsigned int)__popc((unsigned int)(half ? (m >> 32) : m)) << (8 * (b - 1));
+      }
+      if (hl == 0 && cc < ncell) cell_sub[cc] = (int)packed;
+      if (hl < cnt) {
+        const int dst = s + rank;
+        x4o[dst] = xp; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+      }
+      continue;
+    }
+    for (int cc = c0; cc < c0 + 2 && cc < ncell; ++cc) {
+      const int s = cc == c0 ? s0 : s1, cnt = min(cc == c0 ? cnt0 : cnt1, 64);
+      int pi = 0, tg = 0, key = 0x7fffffff;
+      Vec4<R> xp = mk4<R>(0, 0, 0, 0);
+      if (l < cnt) { pi = bucket[(size_t)cc * bcap + l]; tg = tag[pi]; xp = x4[pi]; key = sort_key<R>(xp, cc, box, tg); }
+      int rank = 0;
+      for (int k = 0; k < cnt; ++k) { const int tk = __shfl(key, k); rank += (tk < key) ? 1 : 0; }
+      const int bin = key >> 29;
+      unsigned int packed = 0;
+#pragma unroll
+      for (int b = 1; b < NSUB; ++b) packed |= (unsigned int)__popcll(__ballot(l < cnt && bin < b)) << (8 * (b - 1));
+      if (l == 0) cell_sub[cc] = (int)packed;
+      if (l < cnt) {
+        const int dst = s + rank;
+        x4o[dst] = xp; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
       }
     }
   }
@@ -1793,7 +1860,7 @@ template <typename R> struct FusedArgs {
   double half_skin; R rl2;
   Vec4<R> *x4, *v4, *x4o, *v4o, *x0;
   int *tag, *tago, *rtag; int4 *img4, *img4o;
-  int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot, *cell_sub;
+  int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot, *cell_sub, *cell_n, *bucket; int bcap;
   TileLDS<R>* desc; const int *excl_start, *excl_list;
   unsigned short* nl16; int *nnh, *nlist, *nn;
   unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
@@ -1820,7 +1887,7 @@ __device__ __forceinline__ void seg_offsets(const int* tot, int nseg, int* s_off
 // block-parallel local scans: segment `seg` = 2^shift consecutive items; loc[] = exclusive prefix inside
 // the segment, tot[seg] = segment sum.  zero != 0: the counts are cleared for the next rebuild.
 template <int BS>
-__device__ __forceinline__ void seg_scan(int* cnt, int nitem, int shift, int* loc, int* tot, bool zero) {
+__device__ __forceinline__ void seg_scan(int* cnt, int nitem, int shift, int* loc, int* tot, bool zero, int* cnt_copy = nullptr) {
   const int per = 1 << shift, nseg = (nitem + per - 1) >> shift;
   for (int seg = blockIdx.x; seg < nseg; seg += gridDim.x) {
     const int lo = seg << shift, hi = min(nitem, lo + per);
@@ -1828,7 +1895,7 @@ __device__ __forceinline__ void seg_scan(int* cnt, int nitem, int shift, int* lo
     for (int base = lo; base < hi; base += BS) {
       const int k = base + (int)threadIdx.x;
       int v = 0;
-      if (k < hi) { v = cnt[k]; if (zero) cnt[k] = 0; }
+      if (k < hi) { v = cnt[k]; if (zero) cnt[k] = 0; if (cnt_copy) cnt_copy[k] = v; }
       int t;
       const int ex = block_scan_excl<BS>(v, &t);
       if (k < hi) loc[k] = carry + ex;
@@ -1869,7 +1936,7 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
   if (b == 0 && t == 0) a.gb->stamp[0] = wall_clock64();
   if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
   if (b == 0 && t == 8) ctl->bwork_count = 0;
-  { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl); }
+  { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl, a.bucket, a.bcap); }
   if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[1] = wall_clock64();
   // every workgroup has taken its decision: the control block may change now
   if (b == 0 && t == 0) {
@@ -1877,29 +1944,19 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
     ctl->rebuild_count++; ctl->need_rebuild = 1;
   }
 
-  // ---- P2: cell counts -> per-segment exclusive prefixes + segment totals ----
-  seg_scan<BS>(a.cell_cnt, a.ncell, a.seg_shift, a.cell_loc, a.btot, true);
+  // ---- P2: cell counts -> per-segment exclusive prefixes + segment totals (counts kept in cell_n) ----
+  seg_scan<BS>(a.cell_cnt, a.ncell, a.seg_shift, a.cell_loc, a.btot, true, a.cell_n);
   if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[2] = wall_clock64();
+  if (b == 0 && t == 0) a.gb->stamp[3] = a.gb->stamp[2];   // (the placement pass is gone: members sit in the bucket rows)
 
-  // ---- P3: final cell_start of the own segments; particle -> sorted position ----
+  // ---- P4: cell_start, canonical order inside every cell + gather (members from the bucket rows filled in P1);
+  //          home-particle count of every tile ----
   {
     const int per = 1 << a.seg_shift, nseg = (a.ncell + per - 1) >> a.seg_shift;
     seg_offsets<BS>(a.btot, nseg, s_off);
-    for (int seg = b; seg < nseg; seg += NB) {
-      const int lo = seg << a.seg_shift, hi = min(a.ncell, lo + per);
-      for (int c = lo + t; c < hi; c += BS) a.cell_start[c] = a.cell_loc[c] + s_off[seg];
-    }
     if (b == 0 && t == 0) a.cell_start[a.ncell] = s_off[nseg];
-    for (int i = b * BS + t; i < a.n; i += NB * BS) {
-      const int c = a.cell_of[i];
-      if (c >= 0) a.perm[a.cell_loc[c] + s_off[c >> a.seg_shift] + a.slot_of[i]] = i;
-    }
-  }
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[3] = wall_clock64();
-
-  // ---- P4: canonical order inside every cell + gather; home-particle count of every tile ----
-  dev_sort_gather<R>(a.ncell, a.cell_start, a.perm, a.x4, a.v4, a.tag, a.img4, a.x4o, a.v4o, a.tago, a.img4o, a.box, a.cell_sub);
-  {
+    dev_sort_gather_bucket<R>(a.ncell, a.cell_loc, a.cell_n, s_off, a.seg_shift, a.bucket, a.bcap, a.cell_start, a.x4, a.v4, a.tag, a.img4,
+                              a.x4o, a.v4o, a.tago, a.img4o, a.box, a.cell_sub);
     const int nx = a.box.nc[0], ny = a.box.nc[1], nz = a.box.nc[2];
     const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
     for (int tile = b * BS + t; tile < a.ntiles; tile += NB * BS) {
@@ -1909,20 +1966,17 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
       int nh = 0;
       for (int hzi = 0; hzi < hz; ++hzi) for (int hyi = 0; hyi < hy; ++hyi) {
         const int c0 = ((cz0 + hzi) * ny + (cy0 + hyi)) * nx + cx0;
-        nh += a.cell_start[c0 + hx] - a.cell_start[c0];
+        for (int k = 0; k < hx; ++k) nh += a.cell_n[c0 + k];
       }
       a.tn[tile] = nh;
     }
   }
   if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[4] = wall_clock64();
 
-  // ---- P5: copy back (+ tag -> index map, reference positions), tile descriptors, tile-count scan ----
-  for (int k = b * BS + t; k < a.n; k += NB * BS) {
-    const Vec4<R> xk = a.x4o[k];
-    a.x4[k] = xk; if (a.x0) a.x0[k] = xk;
-    a.v4[k] = a.v4o[k]; a.img4[k] = a.img4o[k];
-    const int tg = a.tago[k]; a.tag[k] = tg; a.rtag[tg] = k;
-  }
+  // ---- P5: tag -> index map, tile descriptors, tile-count scan.  The sorted arrays stay in x4o/v4o/tago/img4o for
+  //          the list build; they are copied back into the live arrays at the END of P6, where workgroups that ran
+  //          out of tiles would otherwise idle ----
+  for (int k = b * BS + t; k < a.n; k += NB * BS) a.rtag[a.tago[k]] = k;
   for (int tile = b; tile < a.ntiles; tile += NB) {
     __syncthreads();
     tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl, a.cell_sub);
@@ -1938,7 +1992,7 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
   {
     const int tper = 1 << a.tseg_shift, ntseg = (a.ntiles + tper - 1) >> a.tseg_shift;
     seg_offsets<BS>(a.tbtot, ntseg, s_off);
-    if (a.nbent > 0) dev_bonded_prep<BS>(0, a.n, a.tag, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl);   // rtag is complete since the last barrier
+    if (a.nbent > 0) dev_bonded_prep<BS>(0, a.n, a.tago, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl);   // rtag is complete since the last barrier
     const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
     for (;;) {
       __syncthreads();
@@ -1959,11 +2013,17 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
       tile_load_desc<R>(T, a.desc, tile);
       __syncthreads();
       if (t == 0) { const int hb = a.tloc[tile] + s_off[tile >> a.tseg_shift]; T.geom[5] = hb; a.desc[tile].geom[5] = hb; }
-      if constexpr (sizeof(R) == 4) tile_fill_pairs<BS>(T, reinterpret_cast<float*>(sx), a.CAP, a.x4);
-      else tile_fill<R, BS, true>(T, sx, a.CAP, a.x4, 1);
+      if constexpr (sizeof(R) == 4) tile_fill_pairs<BS>(T, reinterpret_cast<float*>(sx), a.CAP, a.x4o);
+      else tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
       __syncthreads();
-      dev_nlist_tile<R, BS>(T, sx, a.tag, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
-                            a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4);
+      dev_nlist_tile<R, BS>(T, sx, a.tago, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
+                            a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o);
+    }
+    // copy-back (+ reference positions): every workgroup moves its share once it has no tile left
+    for (int k = b * BS + t; k < a.n; k += NB * BS) {
+      const Vec4<R> xk = a.x4o[k];
+      a.x4[k] = xk; if (a.x0) a.x0[k] = xk;
+      a.v4[k] = a.v4o[k]; a.img4[k] = a.img4o[k]; a.tag[k] = a.tago[k];
     }
   }
   if (b == 0 && t == 0) a.gb->stamp[6] = wall_clock64();

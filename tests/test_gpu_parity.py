@@ -2,6 +2,8 @@
 inputs.  Tolerances: fp64 mode 1e-10 relative (summation order only); fp32 mode 2e-4 of the
 largest force (fp32 pair arithmetic, fp64 bonded).  Integer results (lists, events, states,
 types) must be bit-identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -922,7 +924,7 @@ def test_bench_multi_process_over_ipc_on_one_gpu(tmp_path, nranks):
         port = sk.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", CHEM_TRANSPORT="ipc")
-    common = ["--steps", "40", "--warmup", "10", "--n", "64000", "--interval", "20", "--equil", "100", "--cpu-steps", "0", "--f64-steps", "0"]
+    common = ["--steps", "40", "--warmup", "10", "--particles", "64000", "--interval", "20", "--equil", "100", "--cpu-steps", "0", "--f64-steps", "0"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nranks)] + common
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
