@@ -290,8 +290,10 @@ template <typename R> struct CtxT : Ctx {
     int g = std::min(per_cu * prop.multiProcessorCount, 1024) / 8 * 8;
     if (g < 8) return;
     fused_grid = g;
-    auto shift_for = [&](int nitem) { int sh = 0; while (((nitem + (1 << sh) - 1) >> sh) > g) ++sh; return sh; };
-    seg_shift = shift_for(box.ncell); tseg_shift = shift_for(ntiles);
+    auto shift_for = [&](int nitem, int lo, int maxseg) { int sh = lo; while (((nitem + (1 << sh) - 1) >> sh) > maxseg) ++sh; return sh; };
+    // cell segments: 64 cells (the prefix inside a segment is one wave reduction in the sort phase), more when that
+    // would give more than 1024 segments; tile segments: <= 1024 of them
+    seg_shift = shift_for(box.ncell, 6, 1024); tseg_shift = shift_for(ntiles, 0, 1024);
     cell_loc.alloc(box.ncell + 1); seg_tot.alloc(1024); tile_n.alloc(ntiles + 1); tile_loc.alloc(ntiles + 1); tseg_tot.alloc(1024);
     // bucket rows of the binning pass: 64 members per cell = what one wave sorts (the LDS tiles already require a mean
     // cell occupancy far below that); a fuller cell raises ctl->bucket_overflow and the unfused chain takes over
@@ -299,6 +301,7 @@ template <typename R> struct CtxT : Ctx {
     bcap = 64;
     bucket.alloc((size_t)box.ncell * bcap);
     if (!gbar.p) { gbar.alloc(1); HIPCHK(hipMemsetAsync(gbar.p, 0, sizeof(GridBar), stream)); }
+    HIPCHK(hipMemsetAsync(seg_tot.p, 0, sizeof(int) * 1024, stream));
     use_fused = true;
   }
   void launch_rebuild_fused() {

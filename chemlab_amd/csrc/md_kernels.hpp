@@ -250,7 +250,7 @@ template <typename R> struct MigBuf { int* count; Vec4<R>* x; Vec4<R>* v; int4* 
 template <typename R>
 __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R>* v4, const int* tag, int4* img4, const Box<R>& box,
                                         int* cell_cnt, int* cell_of, int* slot_of, const MigBuf<R>& mdn, const MigBuf<R>& mup, DevCtl* ctl,
-                                        int* bucket = nullptr, int bcap = 0) {
+                                        int* bucket = nullptr, int bcap = 0, int* seg_tot = nullptr, int seg_shift = 0) {
   // the loop bound is wave-uniform (rounded up) because the slot assignment below uses cross-lane ops
   const int iend = i0 + n;
   for (int ib = i0 + blockIdx.x * blockDim.x; ib < iend; ib += gridDim.x * blockDim.x) {
@@ -308,6 +308,17 @@ __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R
     const int end = above ? lane + __ffsll((long long)above) : 64;        // first head after this lane
     int base = 0;
     if (head && cid >= 0) base = atomicAdd(&cell_cnt[cid], end - start);
+    if (seg_tot) {
+      // particles per segment of 2^seg_shift cells (fused rebuild): one atomic per run of equal SEGMENTS in the wave
+      // (a wave usually sits inside one segment; per-cell-run atomics on the same word serialise in the L2)
+      const int sg = cid >= 0 ? cid >> seg_shift : -1;
+      const int sprev = __shfl_up(sg, 1);
+      const bool shead = lane == 0 || sprev != sg;
+      const unsigned long long shm = __ballot(shead);
+      const unsigned long long sabove = lane == 63 ? 0ull : (shm >> (lane + 1));
+      const int send = sabove ? lane + __ffsll((long long)sabove) : 64;
+      if (shead && sg >= 0) atomicAdd(&seg_tot[sg], send - lane);
+    }
     base = __shfl(base, start);
     if (cid >= 0) {
       const int slot = base + (lane - start);
@@ -498,20 +509,29 @@ __device__ __forceinline__ void dev_sort_gather(int ncell, const int* cell_start
   }
 }
 
-// Fused-rebuild variant: members come from the fixed-capacity bucket rows filled while binning, the cell's first
-// index is computed here (cell_loc + segment offset) and published as cell_start; <= 64 members per cell (bucket
-// capacity is checked at binning time).
+// Fused-rebuild variant: members come from the fixed-capacity bucket rows filled while binning.  A cell's first index
+// = offset of its segment (s_off, from the per-segment totals of the binning pass) + the counts of the cells in front
+// of it inside the segment (<= 63 values: one load per lane and a wave reduction) -- no separate scan phase; it is
+// published as cell_start, and the tag -> index map is written with the gather.  <= 64 members per cell (checked at
+// binning time).
 template <typename R>
-__device__ __forceinline__ void dev_sort_gather_bucket(int ncell, const int* cell_loc, const int* cell_n, const int* s_off, int seg_shift,
+__device__ __forceinline__ void dev_sort_gather_bucket(int ncell, const int* cell_cnt, const int* s_off, int seg_shift,
                                                        const int* bucket, int bcap, int* cell_start, const Vec4<R>* x4, const Vec4<R>* v4,
                                                        const int* tag, const int4* img4, Vec4<R>* x4o, Vec4<R>* v4o, int* tago, int4* img4o,
-                                                       const Box<R>& box, int* cell_sub) {
+                                                       int* rtag, const Box<R>& box, int* cell_sub) {
   const int l = lane_id(), hl = l & 31, half = l >> 5;
   const int nw = gridDim.x * (blockDim.x >> 6);
+  const int per = 1 << seg_shift;
   for (int c0 = 2 * (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); c0 < ncell; c0 += 2 * nw) {
     const bool two = c0 + 1 < ncell;
-    const int cnt0 = cell_n[c0], cnt1 = two ? cell_n[c0 + 1] : 0;
-    const int s0 = cell_loc[c0] + s_off[c0 >> seg_shift], s1 = two ? cell_loc[c0 + 1] + s_off[(c0 + 1) >> seg_shift] : s0 + cnt0;
+    // c0 is even and segments hold an even number (>= 2) of cells: c0 and c0 + 1 share a segment
+    const int seg = c0 >> seg_shift, lo = seg << seg_shift;
+    int before = 0;
+    for (int k = lo + l; k < c0; k += 64) before += cell_cnt[k];     // per <= 64: one trip
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    (void)per;
+    const int cnt0 = cell_cnt[c0], cnt1 = two ? cell_cnt[c0 + 1] : 0;
+    const int s0 = s_off[seg] + before, s1 = s0 + cnt0;
     if (l == 0) { cell_start[c0] = s0; if (two) cell_start[c0 + 1] = s1; }
     if (cnt0 <= 32 && cnt1 <= 32) {
       const int s = half ? s1 : s0, cnt = half ? cnt1 : cnt0, cmax = cnt0 > cnt1 ? cnt0 : cnt1;
@@ -531,7 +551,7 @@ __device__ __forceinline__ void dev_sort_gather_bucket(int ncell, const int* cel
       if (hl == 0 && cc < ncell) cell_sub[cc] = (int)packed;
       if (hl < cnt) {
         const int dst = s + rank;
-        x4o[dst] = xp; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+        x4o[dst] = xp; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi]; rtag[tg] = dst;
       }
       continue;
     }
@@ -549,7 +569,7 @@ __device__ __forceinline__ void dev_sort_gather_bucket(int ncell, const int* cel
       if (l == 0) cell_sub[cc] = (int)packed;
       if (l < cnt) {
         const int dst = s + rank;
-        x4o[dst] = xp; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi];
+        x4o[dst] = xp; v4o[dst] = v4[pi]; tago[dst] = tg; img4o[dst] = img4[pi]; rtag[tg] = dst;
       }
     }
   }
@@ -1932,31 +1952,34 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
     return;
   }
 
-  // ---- P1: bin ----
+  // ---- P1: bin.  Members go straight into the bucket row of their cell; per-segment particle totals are
+  //          accumulated beside the cell counts, so that no scan phase is needed afterwards ----
   if (b == 0 && t == 0) a.gb->stamp[0] = wall_clock64();
   if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
   if (b == 0 && t == 8) ctl->bwork_count = 0;
-  { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl, a.bucket, a.bcap); }
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[1] = wall_clock64();
+  { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl, a.bucket, a.bcap, a.btot, a.seg_shift); }
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) { const long long st = wall_clock64(); a.gb->stamp[1] = st; a.gb->stamp[2] = st; a.gb->stamp[3] = st; }
+  if (ctl->bucket_overflow) {
+    // a cell is fuller than a bucket row: nothing but the counters has been touched yet -- clear them and leave; the
+    // host redoes this rebuild with the unfused chain (force_rebuild stays set)
+    for (int k = b * BS + t; k < a.ncell; k += NB * BS) a.cell_cnt[k] = 0;
+    if (b == 0) for (int k = t; k < 1024; k += BS) a.btot[k] = 0;
+    if (b == 0 && t == 0) { ctl->need_rebuild = 1; ctl->force_rebuild = 1; }
+    return;
+  }
   // every workgroup has taken its decision: the control block may change now
   if (b == 0 && t == 0) {
     ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = 0.0; ctl->acc_maxdist = 0.0; ctl->force_rebuild = 0;
     ctl->rebuild_count++; ctl->need_rebuild = 1;
   }
 
-  // ---- P2: cell counts -> per-segment exclusive prefixes + segment totals (counts kept in cell_n) ----
-  seg_scan<BS>(a.cell_cnt, a.ncell, a.seg_shift, a.cell_loc, a.btot, true, a.cell_n);
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[2] = wall_clock64();
-  if (b == 0 && t == 0) a.gb->stamp[3] = a.gb->stamp[2];   // (the placement pass is gone: members sit in the bucket rows)
-
-  // ---- P4: cell_start, canonical order inside every cell + gather (members from the bucket rows filled in P1);
-  //          home-particle count of every tile ----
+  // ---- P4: cell_start, canonical order inside every cell + gather + tag -> index map; home count of every tile ----
   {
-    const int per = 1 << a.seg_shift, nseg = (a.ncell + per - 1) >> a.seg_shift;
+    const int nseg = (a.ncell + (1 << a.seg_shift) - 1) >> a.seg_shift;
     seg_offsets<BS>(a.btot, nseg, s_off);
     if (b == 0 && t == 0) a.cell_start[a.ncell] = s_off[nseg];
-    dev_sort_gather_bucket<R>(a.ncell, a.cell_loc, a.cell_n, s_off, a.seg_shift, a.bucket, a.bcap, a.cell_start, a.x4, a.v4, a.tag, a.img4,
-                              a.x4o, a.v4o, a.tago, a.img4o, a.box, a.cell_sub);
+    dev_sort_gather_bucket<R>(a.ncell, a.cell_cnt, s_off, a.seg_shift, a.bucket, a.bcap, a.cell_start, a.x4, a.v4, a.tag, a.img4,
+                              a.x4o, a.v4o, a.tago, a.img4o, a.rtag, a.box, a.cell_sub);
     const int nx = a.box.nc[0], ny = a.box.nc[1], nz = a.box.nc[2];
     const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
     for (int tile = b * BS + t; tile < a.ntiles; tile += NB * BS) {
@@ -1966,32 +1989,36 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
       int nh = 0;
       for (int hzi = 0; hzi < hz; ++hzi) for (int hyi = 0; hyi < hy; ++hyi) {
         const int c0 = ((cz0 + hzi) * ny + (cy0 + hyi)) * nx + cx0;
-        for (int k = 0; k < hx; ++k) nh += a.cell_n[c0 + k];
+        for (int k = 0; k < hx; ++k) nh += a.cell_cnt[c0 + k];
       }
       a.tn[tile] = nh;
     }
   }
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[4] = wall_clock64();
+  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) { const long long st = wall_clock64(); a.gb->stamp[4] = st; a.gb->stamp[5] = st; }
 
-  // ---- P5: tag -> index map, tile descriptors, tile-count scan.  The sorted arrays stay in x4o/v4o/tago/img4o for
-  //          the list build; they are copied back into the live arrays at the END of P6, where workgroups that ran
-  //          out of tiles would otherwise idle ----
-  for (int k = b * BS + t; k < a.n; k += NB * BS) a.rtag[a.tago[k]] = k;
-  for (int tile = b; tile < a.ntiles; tile += NB) {
-    __syncthreads();
-    tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl, a.cell_sub);
-    const int* src = reinterpret_cast<const int*>(&T);
-    int* dst = reinterpret_cast<int*>(&a.desc[tile]);
-    for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
-  }
-  seg_scan<BS>(a.tn, a.ntiles, a.tseg_shift, a.tloc, a.tbtot, false);
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) a.gb->stamp[5] = wall_clock64();
-
-  // ---- P6: list build; tiles are handed out dynamically, each XCD first drains its own contiguous
-  //          range of tiles (L2 locality, see xcd_remap) and then helps the others ----
+  // ---- P6: tile descriptors + list build.  Tiles are handed out dynamically, each XCD first drains its own contiguous
+  //          range of tiles (L2 locality, see xcd_remap) and then helps the others.  The counts of this rebuild are
+  //          cleared for the next one; the sorted arrays (x4o/v4o/tago/img4o) are read in place and copied back into
+  //          the live arrays by workgroups that have run out of tiles ----
   {
+    for (int k = b * BS + t; k < a.ncell; k += NB * BS) a.cell_cnt[k] = 0;
+    if (b == 0) for (int k = t; k < 1024; k += BS) a.btot[k] = 0;
+    // base of every tile's region in the transposed list = exclusive prefix of the home counts: segment totals of
+    // 2^tseg_shift tiles are summed by every workgroup for itself (a few KB of reads), the rest at claim time
     const int tper = 1 << a.tseg_shift, ntseg = (a.ntiles + tper - 1) >> a.tseg_shift;
-    seg_offsets<BS>(a.tbtot, ntseg, s_off);
+    {
+      int carry = 0;
+      for (int base = 0; base < ntseg; base += BS) {
+        const int k = base + t;
+        int v = 0;
+        if (k < ntseg) for (int j = k << a.tseg_shift; j < min(a.ntiles, (k + 1) << a.tseg_shift); ++j) v += a.tn[j];
+        int tot;
+        const int ex = block_scan_excl<BS>(v, &tot);
+        if (k < ntseg) s_off[k] = carry + ex;
+        carry += tot;
+      }
+      __syncthreads();
+    }
     if (a.nbent > 0) dev_bonded_prep<BS>(0, a.n, a.tago, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl);   // rtag is complete since the last barrier
     const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
     for (;;) {
@@ -2010,9 +2037,18 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
       __syncthreads();
       const int tile = s_tile;
       if (tile < 0) break;
-      tile_load_desc<R>(T, a.desc, tile);
+      tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl, a.cell_sub);      // ends with a workgroup barrier
+      if (t == 0) {
+        int hb = s_off[tile >> a.tseg_shift];
+        for (int j = (tile >> a.tseg_shift) << a.tseg_shift; j < tile; ++j) hb += a.tn[j];
+        T.geom[5] = hb;
+      }
       __syncthreads();
-      if (t == 0) { const int hb = a.tloc[tile] + s_off[tile >> a.tseg_shift]; T.geom[5] = hb; a.desc[tile].geom[5] = hb; }
+      {   // the descriptor every force launch until the next rebuild reads
+        const int* src = reinterpret_cast<const int*>(&T);
+        int* dst = reinterpret_cast<int*>(&a.desc[tile]);
+        for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
+      }
       if constexpr (sizeof(R) == 4) tile_fill_pairs<BS>(T, reinterpret_cast<float*>(sx), a.CAP, a.x4o);
       else tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
       __syncthreads();

@@ -1,6 +1,9 @@
 """GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on identical seeded
-inputs.  Tolerances: fp64 mode 1e-10 relative (summation order only); fp32 mode 2e-4 of the
-largest force (fp32 pair arithmetic, fp64 bonded).  Integer results (lists, events, states,
+inputs.  Tolerances: fp64 mode 1e-10 relative (summation order only); fp32 mode 5e-5 of the
+largest force for pair forces (fp32 coordinates and pair arithmetic; SURVEY App. E asks 1e-5, which fp32
+absolute coordinates cannot give: one ulp of a coordinate at x ~ 30 is 2e-6 and the LJ force changes by
+~13 ulp/r per pair), 5e-4 only where K = 1.6e5 bonds amplify the same coordinate ulp (the pair-only
+component of those systems is asserted separately at 5e-5).  Integer results (lists, events, states,
 types) must be bit-identical."""
 import os
 
@@ -13,7 +16,8 @@ from helpers import sorted_events, total_epot
 
 pytestmark = pytest.mark.gpu
 
-TOL = {64: 1e-10, 32: 2e-4}
+TOL = {64: 1e-10, 32: 5e-5}
+TOL_STIFF32 = 5e-4      # systems with K = 1.6e5 harmonic bonds (mf/espp_cg_1 force field), fp32 coordinates
 
 
 def both(make_gpu, make_oracle, spec, prec, **kw):
@@ -108,7 +112,12 @@ def test_tabulated_and_bonded_polymer(make_gpu, make_oracle, prec):
     spec = W.polymer_melt(n_chains=128, chain_len=32, seed=3)   # 4096 beads
     g, o, h = both(make_gpu, make_oracle, spec, prec, thermostat=False)
     g.run(0); o.run(0)
-    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[prec]
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < (TOL[64] if prec == 64 else TOL_STIFF32)
+    if prec == 32:      # the tabulated pair forces alone (same exclusions, bonded lists without parameters removed)
+        pair_only = dict(spec, lists=[])
+        g2, o2, _ = both(make_gpu, make_oracle, pair_only, 32, thermostat=False)
+        g2.run(0); o2.run(0)
+        assert rel_err(g2.get_state("FORCE"), o2.get_state("FORCE")) < TOL[32]
     og, oo = g.observe(), o.observe()
     for k in range(2):
         assert og["epot_list"][k] == pytest.approx(oo["epot_list"][k], rel=1e-11 if prec == 64 else 1e-5)
@@ -368,7 +377,7 @@ def test_dd_self_bonded_chains_fp32(make_gpu, make_oracle):
     g.set_option("dd_self", 1)
     W.apply(spec, g, thermostat=False); W.apply(spec, o, thermostat=False)
     g.run(0); o.run(0)
-    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[32]
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL_STIFF32
     g.run(40); o.run(40)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 2e-4
 
@@ -469,10 +478,14 @@ def test_dd_multi_rank_in_process_reactive(make_gpu, make_oracle, chunks):
 
 @pytest.mark.parametrize("example,argv,min_events", [
     ("chain_growth_catalytic", ["@params", "--run=2500", "--start_ar=500"], 100),
-    ("mf_espp_cg_1", ["@params", "--run=3000", "--start_ar=1000", "--int_step=500", "--energy_collect=500", "--trj_collect=1000", "--rng_seed=7"], 5)])
+    ("mf_espp_cg_1", ["@params", "--run=3000", "--start_ar=1000", "--int_step=500", "--energy_collect=500", "--trj_collect=1000", "--rng_seed=7"], 5),
+    # C1 (BASELINE configs[0]): examples/atrp_lj with its ChangeNeighboursProperty extension; the ATRPActivator is out of
+    # scope, a hooks.py (start_simulation.py:214-228) creates the initiators the way examples/atrp_lj/hooks.py does
+    ("atrp_lj", ["@params", "--run=1000", "--maximum_conversion=", "--rng_seed=11"], 5)])
 def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mod, example, argv, min_events):
     """The py3 start_simulation driver (readers -> espressopp-shaped shim -> C ABI) on shipped example inputs
-    (LJ chain growth; tabulated non-bonded melt with Langevin at 800 K): HIP engine (fp64) vs the oracle behind the same shim."""
+    (LJ chain growth; tabulated non-bonded melt with Langevin at 800 K; ATRP trimer melt with neighbour property changes and
+    registered angle spawning): HIP engine (fp64) vs the oracle behind the same shim."""
     import os, shutil
     from chemlab_amd import espp, start_simulation
     from chemlab_amd.engine import Engine
@@ -481,6 +494,21 @@ def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mo
     for name, fac in (("gpu", lambda: Engine(device=0, precision=64)), ("oracle", lambda: oracle_mod.OracleEngine())):
         d = tmp_path / name
         shutil.copytree(gold, str(d))
+        if example == "atrp_lj":
+            cfg = (d / "atrp.cfg").read_text().replace("extensions=atrp,change_neighbour_type", "extensions=change_neighbour_type")
+            (d / "atrp.cfg").write_text(cfg)
+            os.makedirs(str(d / "data"), exist_ok=True)
+            (d / "hooks.py").write_text(
+                "def hook_init_reaction(system, integrator, ar, topol, args):\n"
+                "    n2t = topol.atomsym_atomtype\n"
+                "    for mol in range(40):\n"
+                "        for k, (name, state) in enumerate((('FA', 3), ('PL', 2), ('PA', None))):\n"
+                "            pid = 3 * mol * 7 + 1 + k\n"
+                "            system.storage.modifyParticle(pid, 'type', n2t[name])\n"
+                "            system.storage.modifyParticle(pid, 'mass', topol.gt.atomtypes[name]['mass'])\n"
+                "            if state is not None:\n"
+                "                system.storage.modifyParticle(pid, 'state', state)\n"
+                "    return True\n")
         monkeypatch.chdir(d)
         espp.set_engine_factory(fac)
         try:
@@ -678,7 +706,12 @@ def test_dense_slab_grows_the_tile_capacity(make_gpu, make_oracle, prec):
 
 # ---- BASELINE.json configs[1..3] at their full sizes (production precision fp32 vs the fp64 oracle) ------
 def test_baseline_c2_32k_lj_melt(make_gpu, make_oracle):
-    spec = W.lj_melt(n=32000, rho=0.8, seed=21)
+    spec = W.lj_melt(n=32000, rho=0.8, seed=21, gamma=1.0)
+    # a MELT, as BASELINE.json names the configuration: the fcc start is melted first (400 Langevin steps at T = 1 on
+    # the HIP path) and both sides then start from that configuration.  (On the near-perfect lattice itself the pair
+    # forces of ~20 cancel to net forces below 1, and an error budget relative to the largest NET force is meaningless.)
+    m = make_gpu(32); W.apply(spec, m); m.run(400)
+    spec = dict(spec, pos=m.get_state("POS"), vel=m.get_state("VEL"))
     g, o, _ = both(make_gpu, make_oracle, spec, 32, thermostat=False)
     g.run(0); o.run(0)
     assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[32]
@@ -695,12 +728,19 @@ def test_baseline_c3_128k_tabulated_polymer_melt(make_gpu, make_oracle):
     g.run(0); o.run(0)
     # tolerance 5e-4 of the largest force here: K = 1.6e5 bonds turn the fp32 ulp of a coordinate (4e-6 at x ~ 33)
     # into a force error of 2 K ulp ~ 1.2 on forces of ~3e4; the arithmetic itself is fp64 for bonded terms
-    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < 5e-4
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL_STIFF32
     og, oo = g.observe(), o.observe()
     for k in range(2):
         assert og["epot_list"][k] == pytest.approx(oo["epot_list"][k], rel=1e-5)
     assert og["epot_tab"] == pytest.approx(oo["epot_tab"], rel=1e-4, abs=1e-2)
     assert og["list_size"] == oo["list_size"] == [4000 * 31, 4000 * 30]
+    g.run(20); o.run(20)                                      # 20 steps of the stiff-bond dynamics, a rebuild inside
+    assert g.timers()["rebuilds"] == o.timers()["rebuilds"]
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-4
+    # the tabulated pair component alone at the pair tolerance (same particles and exclusions, no bonded lists)
+    g2, o2, _ = both(make_gpu, make_oracle, dict(spec, lists=[]), 32, thermostat=False)
+    g2.run(0); o2.run(0)
+    assert rel_err(g2.get_state("FORCE"), o2.get_state("FORCE")) < TOL[32]
 
 
 def test_baseline_c4_256k_reactive_one_reaction_step(make_gpu, make_oracle):
@@ -722,6 +762,28 @@ def test_baseline_c4_256k_reactive_one_reaction_step(make_gpu, make_oracle):
     assert np.array_equal(g.get_state("TYPE"), o.get_state("TYPE"))
     assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
     assert np.array_equal(g.get_exclusions(), o.get_exclusions())
+
+
+def test_baseline_c4_256k_forces_energy_and_reactive_trajectory(make_gpu, make_oracle):
+    """C4 at full size in production precision: fp32 pair forces with the A-B / A-D pairs switched off
+    (chain_growth_catalytic/topol.top:15-17), energy and virial, then 24 Langevin steps across two reaction steps:
+    same event log, positions within the fp32 trajectory tolerance."""
+    spec = W.reactive_melt(n=256000, rho=0.8, seed=6, interval=12)
+    g, o, h = both(make_gpu, make_oracle, spec, 32)
+    g.run(0); o.run(0)
+    gf, of = g.get_state("FORCE"), o.get_state("FORCE")
+    # the thermostat adds the same keyed noise on both sides (evaluation phase 0); pair part from the lists
+    assert rel_err(gf, of) < TOL[32]
+    og, oo = g.observe(), o.observe()
+    assert og["epot_lj"] == pytest.approx(oo["epot_lj"], rel=2e-6)
+    assert og["virial_nb"] == pytest.approx(oo["virial_nb"], rel=1e-5)
+    g.run(24); o.run(24)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 10000 and set(e[0] for e in eo) == {12, 24}
+    # fp32 positions can flip a pair across the reaction radius: the logs agree except for a handful of borderline pairs
+    sg, so = {e[:4] for e in eg}, {e[:4] for e in eo}
+    assert len(sg ^ so) <= max(4, len(so) // 2000)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-4
 
 
 def test_dd_eight_slabs_at_bench_size_in_process(make_gpu):
