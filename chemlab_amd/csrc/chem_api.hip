@@ -92,11 +92,27 @@ struct Ctx {
   int interval = 0, nearest = 1, max_per_interval = 0; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
   std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty (chem_reaction_neighbour_change)
-  std::vector<chem_event> events;   // expanded, canonical order (filled lazily from raw_events)
-  struct RawEvents { int64_t step; std::vector<int32_t> a, b, r; std::vector<double> d2; std::vector<int8_t> intra; };   // SoA copy of the device records
+  std::vector<chem_event> events;   // expanded, canonical order (filled lazily from the arena by chem_get_events)
+  // event arena: SoA copy of the device records of every reaction step, appended in device order (amortised growth:
+  // fresh vectors per step cost their page faults every time -- 4 ms for 2.8e5 events); blocks = (step, first index).
+  // The host's type/mass/charge mirrors are brought up to date from it lazily (sync_type_mirrors): chemical states and
+  // types live on the device, the mirrors are only read by typed lists, tuple spawning and read-back paths.
+  struct EventArena {
+    std::vector<int32_t> a, b, r; std::vector<double> d2; std::vector<int8_t> intra;
+    std::vector<std::pair<int64_t, size_t>> blocks; size_t mirror_pos = 0, expanded_blocks = 0;
+    size_t size() const { return a.size(); }
+    void clear() { a.clear(); b.clear(); r.clear(); d2.clear(); intra.clear(); blocks.clear(); mirror_pos = 0; expanded_blocks = 0; }
+  } arena;
   int opt_intra_inter = 0;   // classify every event as intra-/inter-cluster at event time (ar.save_intra_inter_counter)
-  std::vector<RawEvents> raw_events;  // one block per reaction step, device order
-  int64_t n_events = 0;
+  void sync_type_mirrors() {
+    for (size_t k = arena.mirror_pos; k < arena.size(); ++k) {
+      const chem_reaction_desc& d = reactions[arena.r[k]];
+      const int32_t ea = arena.a[k], eb = arena.b[k];
+      if (d.new_type_1 >= 0 && d.new_type_1 != top.type[ea]) { top.type[ea] = d.new_type_1; top.mass[ea] = d.new_mass_1; top.q[ea] = d.new_q_1; }
+      if (d.new_type_2 >= 0 && d.new_type_2 != top.type[eb]) { top.type[eb] = d.new_type_2; top.mass[eb] = d.new_mass_2; top.q[eb] = d.new_q_2; }
+    }
+    arena.mirror_pos = arena.size();
+  }
   int64_t step = 0;
   bool resort = true;
   bool geom_dirty = true, particles_dirty = true, pair_dirty = true, bonded_dirty = true, excl_dirty = true, labels_dirty = true;
@@ -158,9 +174,9 @@ template <typename R> struct CtxT : Ctx {
   // cluster labels of a reaction step are merged on a host thread beside the following MD steps;
   // joined (and uploaded) before the next reaction scan and before any other API call
   std::thread label_thr; bool labels_pending = false; std::exception_ptr label_err;
-  PinnedVec<int32_t> stage_hs, stage_es, stage_el; PinnedVec<HBondedEntry> stage_he; std::vector<HBondedParam> stage_hp;   // host staging of the device tables, reused
   std::vector<std::pair<int32_t, int32_t>> label_bonds; std::vector<int32_t> label_touched;
   void join_async() override {
+    sync_type_mirrors();      // any API call other than chem_run sees current type/mass/charge mirrors
     if (label_thr.joinable()) label_thr.join();
     if (label_err) { std::exception_ptr e = label_err; label_err = nullptr; labels_pending = false; std::rethrow_exception(e); }
     if (labels_pending) {
@@ -325,7 +341,8 @@ template <typename R> struct CtxT : Ctx {
 #define SETA(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
     SETA((k_nlist_tiles<R, 512>));
     SETA((k_react_scan_tiles<R, 512>));
-#define SETB(T, E, M) SETA((k_pair_tiles<R, T, E, 256, M>)); SETA((k_pair_tiles<R, T, E, 512, M>)); SETA((k_pair_tiles<R, T, E, 1024, M>))
+#define SETB(T, E, M) SETA((k_pair_tiles<R, T, E, 256, M>)); SETA((k_pair_tiles<R, T, E, 512, M>)); SETA((k_pair_tiles<R, T, E, 1024, M>)); \
+                      if (T == 1 && !E) SETA((k_pair_tiles<R, 1, false, 512, M, true>))
 #define SETT(E, M) SETB(1, E, M); SETB(2, E, M); SETB(4, E, M); SETB(8, E, M)
     SETT(false, 2); SETT(false, 1); SETT(false, 0); SETT(true, 0);
 #undef SETT
@@ -483,11 +500,9 @@ template <typename R> struct CtxT : Ctx {
     pair_dirty = false;
   }
 
-  void upload_bonded() {
-    std::vector<int32_t> hs; std::vector<HBondedEntry> he; std::vector<HBondedParam> hp;
-    top.build_bonded(hs, he, hp);
-    upload_bonded_from(hs, he, hp);
-  }
+  // ---- per-tag CSR tables built on the device from flat, append-only arrays (md_kernels.hpp "Per-tag CSR tables") ----
+  DBuf<int4> fent; DBuf<int> flist, eslot, bkey, tcnt, tcounts, type_tag; DBuf<SlotKey> skeys; DBuf<int2> epairs;
+  size_t fent_n = 0, epairs_n = 0; std::vector<size_t> list_uploaded; int nslot = 0;
   DBuf<double2> btab_rows; DBuf<double4> btab_info; size_t btab_uploaded = 0;
   BTab btab_view() const { return BTab{btab_rows.p, btab_info.p}; }
   void upload_bond_tables() {
@@ -501,28 +516,104 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipStreamSynchronize(stream));
     btab_uploaded = top.btables.size();
   }
-  template <class VI, class VE> void upload_bonded_from(const VI& hs, const VE& he, const std::vector<HBondedParam>& hp) {
+  template <typename T> static void grow(DBuf<T>& b, size_t used, size_t need, hipStream_t st) {   // keeps the first `used` elements
+    if (need <= b.n) return;
+    DBuf<T> nb; nb.alloc(std::max(need, b.n * 2 + 1024));
+    if (used) HIPCHK(hipMemcpyAsync(nb.p, b.p, used * sizeof(T), hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::swap(b.p, nb.p); std::swap(b.n, nb.n);
+  }
+  DBuf<int> scan_tot;
+  void scan_counts(int n, int* cnt, int* start) {
+    const int nb = cdiv(n, kScanItems);
+    scan_tot.alloc(std::max(nb, 1));
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(1024), 0, stream, n, cnt, start, scan_tot.p);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, stream, nb, scan_tot.p, n, start);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(1024), 0, stream, n, (const int*)scan_tot.p, start);
+  }
+  // full = true: every tuple of every list again (set-up, parameter changes); false: only what the lists gained
+  // since the last call (reaction steps).  Parameter slots are re-resolved against the current particle types on
+  // the device either way.
+  // wait = false: everything is only enqueued (reaction step: the host goes on with its own bookkeeping meanwhile);
+  // the table sizes the host needs (entry and owner counts) are upper bounds from the flat arrays, the kernels
+  // themselves read the exact figures from device memory
+  size_t fent_members = 0;     // sum of arity * (2 for quadruples) over the flat tuples
+  std::vector<HBondedParam> stage_hp; std::vector<HostTopology::HSlotKey> stage_hk; std::vector<int4> stage_ne; std::vector<int> stage_nl;
+  void upload_bonded(bool full = true, bool wait = true) {
     upload_bond_tables();
-    static_assert(sizeof(HBondedEntry) == sizeof(BondedEntry) && sizeof(HBondedParam) == sizeof(BondedParam), "layout");
-    bstart.alloc(hs.size()); bent.alloc(he.size()); bpar.alloc(hp.size());
-    HIPCHK(hipMemcpyAsync(bstart.p, hs.data(), hs.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-    if (!he.empty()) HIPCHK(hipMemcpyAsync(bent.p, he.data(), he.size() * sizeof(BondedEntry), hipMemcpyHostToDevice, stream));
-    if (!hp.empty()) HIPCHK(hipMemcpyAsync(bpar.p, hp.data(), hp.size() * sizeof(BondedParam), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipStreamSynchronize(stream));
-    nbent = (int64_t)he.size();
-    nb_owner = 0;
-    for (size_t t = 0; t + 1 < hs.size(); ++t) nb_owner += hs[t + 1] > hs[t] ? 1 : 0;
-    bwork.alloc(std::max(nb_owner, 1)); bj.alloc(std::max<size_t>(he.size(), 1));
+    // (host staging lives in members: with wait = false the copies may still be in flight when this returns)
+    std::vector<HBondedParam>& hp = stage_hp; std::vector<HostTopology::HSlotKey>& hk = stage_hk;
+    top.build_params(hp, hk);
+    static_assert(sizeof(HBondedParam) == sizeof(BondedParam) && sizeof(HostTopology::HSlotKey) == sizeof(SlotKey), "layout");
+    nslot = (int)hp.size();
+    bpar.alloc(std::max<size_t>(hp.size(), 1)); skeys.alloc(std::max<size_t>(hk.size(), 1));
+    if (nslot) {
+      HIPCHK(hipMemcpyAsync(bpar.p, hp.data(), hp.size() * sizeof(BondedParam), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(skeys.p, hk.data(), hk.size() * sizeof(SlotKey), hipMemcpyHostToDevice, stream));
+    }
+    if (full || list_uploaded.size() != top.lists.size()) { fent_n = 0; fent_members = 0; list_uploaded.assign(top.lists.size(), 0); }
+    std::vector<int4>& ne = stage_ne; std::vector<int>& nl = stage_nl;
+    ne.clear(); nl.clear();
+    bool typed = false;
+    for (size_t li = 0; li < top.lists.size(); ++li) {
+      const HostList& l = top.lists[li];
+      typed |= l.by_types != 0;
+      const size_t have = (size_t)l.size();
+      for (size_t e = list_uploaded[li]; e < have; ++e) {
+        const int32_t* t = &l.ent[e * l.arity];
+        ne.push_back(make_int4(t[0], t[1], l.arity > 2 ? t[2] : -1, l.arity > 3 ? t[3] : -1)); nl.push_back((int)li);
+      }
+      fent_members += (have - list_uploaded[li]) * (size_t)(l.arity == 4 ? 8 : l.arity);
+      list_uploaded[li] = have;
+    }
+    grow(fent, fent_n, fent_n + ne.size(), stream); grow(flist, fent_n, fent_n + ne.size(), stream);
+    if (!ne.empty()) {
+      HIPCHK(hipMemcpyAsync(fent.p + fent_n, ne.data(), ne.size() * sizeof(int4), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipMemcpyAsync(flist.p + fent_n, nl.data(), nl.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+      fent_n += ne.size();
+    }
+    const int nt = nglob > 0 ? nglob : (int)top.n;
+    if (tcnt.n < (size_t)nt + 1) { tcnt.alloc((size_t)nt + 1); HIPCHK(hipMemsetAsync(tcnt.p, 0, sizeof(int) * ((size_t)nt + 1), stream)); }
+    bstart.alloc((size_t)nt + 1); tcounts.alloc(2);
+    if (typed) type_tag.upload(top.type, stream);      // typed lists: the host keeps the type mirrors current (react_step)
+    HIPCHK(hipMemsetAsync(tcounts.p, 0, 2 * sizeof(int), stream));
+    const size_t ub = (fent_n && nslot) ? fent_members : 0;      // upper bound of the entry count (tuples without parameters drop out)
+    if (ub) {
+      const int ne_i = (int)fent_n;
+      eslot.alloc(fent_n); bent.alloc(ub); bkey.alloc(ub);
+      hipLaunchKernelGGL((k_bt_count<R>), dim3(cdiv(ne_i, 256)), dim3(256), 0, stream, ne_i, fent.p, flist.p, nslot, skeys.p, x4.p, rtag.p,
+                         typed ? (const int*)type_tag.p : (const int*)nullptr, eslot.p, tcnt.p);
+      scan_counts(nt, tcnt.p, bstart.p);
+      hipLaunchKernelGGL(k_bt_fill, dim3(cdiv(ne_i, 256)), dim3(256), 0, stream, ne_i, fent.p, eslot.p, skeys.p, bstart.p, tcnt.p, bent.p, bkey.p);
+      hipLaunchKernelGGL(k_bt_sort, dim3(cdiv(nt, 256)), dim3(256), 0, stream, nt, bstart.p, tcnt.p, bent.p, bkey.p, tcounts.p);
+    } else HIPCHK(hipMemsetAsync(bstart.p, 0, sizeof(int) * ((size_t)nt + 1), stream));
+    nbent = (int64_t)ub; nb_owner = (int)std::min<size_t>((size_t)nt, ub);
+    bwork.alloc(std::max(nb_owner, 1)); bj.alloc(std::max<size_t>((size_t)nbent, 1));
     bwork_dirty = true;
     bonded_dirty = false;
+    if (wait) HIPCHK(hipStreamSynchronize(stream));
   }
 
-  void upload_excl() {
-    std::vector<int32_t> es, el;
-    top.build_excl(es, el);
-    excl_start.upload(es, stream); excl_list.upload(el, stream);
-    HIPCHK(hipStreamSynchronize(stream));
-    has_excl = el.empty() ? 0 : 1;
+  void upload_excl(bool full = true, bool wait = true) {
+    if (full) epairs_n = 0;
+    const size_t have = top.excl_log.size();
+    const size_t add = have - epairs_n;
+    grow(epairs, epairs_n, have, stream);
+    static_assert(sizeof(std::pair<int32_t, int32_t>) == sizeof(int2), "layout");
+    if (add) HIPCHK(hipMemcpyAsync(epairs.p + epairs_n, top.excl_log.data() + epairs_n, add * sizeof(int2), hipMemcpyHostToDevice, stream));
+    epairs_n = have;
+    const int nt = nglob > 0 ? nglob : (int)top.n;
+    if (tcnt.n < (size_t)nt + 1) { tcnt.alloc((size_t)nt + 1); HIPCHK(hipMemsetAsync(tcnt.p, 0, sizeof(int) * ((size_t)nt + 1), stream)); }
+    excl_start.alloc((size_t)nt + 1); excl_list.alloc(std::max<size_t>(2 * have, 1));
+    if (have) {
+      const int m = (int)have;
+      hipLaunchKernelGGL(k_ex_count, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, epairs.p, tcnt.p);
+      scan_counts(nt, tcnt.p, excl_start.p);
+      hipLaunchKernelGGL(k_ex_fill, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, epairs.p, excl_start.p, tcnt.p, excl_list.p);
+      hipLaunchKernelGGL(k_ex_sort, dim3(cdiv(nt, 256)), dim3(256), 0, stream, nt, excl_start.p, tcnt.p, excl_list.p);
+    } else HIPCHK(hipMemsetAsync(excl_start.p, 0, sizeof(int) * ((size_t)nt + 1), stream));
+    if (wait) HIPCHK(hipStreamSynchronize(stream));
+    has_excl = have ? 1 : 0;
     excl_dirty = false; resort = true;
   }
 
@@ -775,15 +866,19 @@ template <typename R> struct CtxT : Ctx {
       if (pair_subset == 1) { ts = TileSub{ntxy, ntiles - 2 * ntxy, 0}; nsub = ntiles - 2 * ntxy; }
       else if (pair_subset == 2) { ts = TileSub{0, ntxy, ntiles - ntxy}; nsub = 2 * ntxy; }
       if (nsub <= 0) return 0;
-#define LT(T, M, B) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M>), dim3(nsub), dim3(B), tile_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
-                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, opt_ablate | pair_guard, dbg_on ? dbgbuf.p : (long long*)nullptr, ts)
-#define LTB(T, M) do { if (pair_bs == 256) LT(T, M, 256); else if (pair_bs == 512) LT(T, M, 512); else LT(T, M, 1024); } while (0)
+#define LTD(T, M, B, D) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M, D>), dim3(nsub), dim3(B), tile_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
+                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, pair_guard, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr, ts)
+#define LT(T, M, B) LTD(T, M, B, false)
+      // diagnostics (options debug_stamps / ablate): one instantiation, one lane per particle, 512 threads
+#define LTB(T, M) do { if ((dbg_on || opt_ablate) && !ENERGY) { if (T != 1 || pair_bs != 512) throw ChemError(CHEM_EINVAL, "debug_stamps / ablate need tpp=1 and pair_block=512"); LTD(1, M, 512, true); } \
+                       else if (pair_bs == 256) LT(T, M, 256); else if (pair_bs == 512) LT(T, M, 512); else LT(T, M, 1024); } while (0)
 #define LTT(M) do { switch (tpp) { case 1: LTB(1, M); break; case 2: LTB(2, M); break; case 8: LTB(8, M); break; default: LTB(4, M); break; } } while (0)
       const int mode = ENERGY ? 0 : (uniform_lj ? 2 : (lj_only ? 1 : 0));
       if (mode == 2) LTT(2); else if (mode == 1) LTT(1); else LTT(0);
 #undef LTT
 #undef LTB
 #undef LT
+#undef LTD
       return ntiles;
     }
     const int nb = cdiv((long long)n * tpp, 256);
@@ -798,7 +893,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void compute_forces(bool speculative = false, int subset = 0) {
-    pair_guard = speculative ? 256 : 0;
+    pair_guard = speculative ? 1 : 0;
     pair_subset = subset;
     const int tpp = pick_tpp();
     const bool timed = timed_step && subset == 0;
@@ -954,8 +1049,6 @@ template <typename R> struct CtxT : Ctx {
       }
       // pinned staging of the tables a bond-forming step rebuilds; sized so that growing them (a
       // pinned reallocation costs milliseconds) is rare: one entry per particle to start with
-      stage_hs.reserve((size_t)top.n + 1); stage_es.reserve((size_t)top.n + 1);
-      stage_he.reserve((size_t)top.n); stage_el.reserve((size_t)top.n);
     }
     if (resort) rebuild_now();
     compute_forces();
@@ -1062,7 +1155,8 @@ template <typename R> struct CtxT : Ctx {
       const int region_cap = std::max(1, cand_cap / std::max(ntiles, 1));
       tile_cnt.alloc(ntiles + 1); tile_off.alloc(ntiles + 1);
       hipLaunchKernelGGL((k_react_scan_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, state.p,
-                         res_id.p, mol_id.p, boxd, rs_dev.p, evout.p, region_cap, tile_cnt.p, ctl.p);
+                         res_id.p, mol_id.p, boxd, rs_dev.p, evout.p, region_cap, tile_cnt.p, ctl.p, (R)(0.5 * skin),
+                         has_excl ? (const int*)excl_start.p : (const int*)nullptr, (const int*)excl_list.p);
       hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, stream, ntiles, tile_cnt.p, tile_off.p, ctl.p);
       hipLaunchKernelGGL(k_cand_gather, dim3(std::min(ntiles, 2048)), dim3(256), 0, stream, ntiles, evout.p, region_cap, tile_cnt.p, tile_off.p, cdst, cand_cap, ctl.p);
     } else {
@@ -1158,8 +1252,10 @@ template <typename R> struct CtxT : Ctx {
     }
     HIPCHK(hipStreamSynchronize(stream));
     trc.lap("download");
-    std::vector<Candidate> hev(pin_ev, pin_ev + nev);
-    trc.lap("copy");
+    // the event records are processed where the copy kernel put them (pinned, host-cached memory): no second copy
+    struct Span { Candidate* p; size_t n; Candidate* begin() const { return p; } Candidate* end() const { return p + n; }
+                  Candidate* data() const { return p; } size_t size() const { return n; } Candidate& operator[](size_t k) const { return p[k]; } };
+    const Span hev{pin_ev, (size_t)nev};
     // Host mirrors + topology.  Only bond-forming events need the canonical order now (it fixes
     // the order of the bond lists); the event log itself is put in canonical order lazily
     // by chem_get_events.
@@ -1197,25 +1293,28 @@ template <typename R> struct CtxT : Ctx {
       intra_flags.resize(hev.size());
       for (size_t k = 0; k < hev.size(); ++k) intra_flags[k] = top.mol_id[hev[k].a] == top.mol_id[hev[k].b] ? 1 : 0;
     }
-    auto log_and_mirror = [&] {
-      Ctx::RawEvents blk; blk.step = step;
-      blk.a.resize(hev.size()); blk.b.resize(hev.size()); blk.r.resize(hev.size()); blk.d2.resize(hev.size());
-      for (size_t k = 0; k < hev.size(); ++k) { blk.a[k] = hev[k].a; blk.b[k] = hev[k].b; blk.r[k] = hev[k].r; blk.d2[k] = hev[k].d2; }
-      blk.intra = std::move(intra_flags);
-      raw_events.push_back(std::move(blk)); n_events += (int64_t)hev.size();
-      for (auto& e : hev) {
+    // event log: appended to the arena in device order (canonical order is established lazily by chem_get_events)
+    auto append_event_log = [&] {
+      EventArena& A = arena;
+      const size_t n0 = A.size(), m = hev.size();
+      A.blocks.emplace_back(step, n0);
+      A.a.resize(n0 + m); A.b.resize(n0 + m); A.r.resize(n0 + m); A.d2.resize(n0 + m);
+      if (opt_intra_inter) { A.intra.resize(n0 + m); std::copy(intra_flags.begin(), intra_flags.end(), A.intra.begin() + n0); }
+      for (size_t k = 0; k < m; ++k) {
+        const Candidate& e = hev[k];
+        A.a[n0 + k] = e.a; A.b[n0 + k] = e.b; A.r[n0 + k] = e.r; A.d2[n0 + k] = e.d2;
         const chem_reaction_desc& d = reactions[e.r];
-        if (d.new_type_1 >= 0 && d.new_type_1 != top.type[e.a]) { top.type[e.a] = d.new_type_1; top.mass[e.a] = d.new_mass_1; top.q[e.a] = d.new_q_1; types_changed = true; }
-        if (d.new_type_2 >= 0 && d.new_type_2 != top.type[e.b]) { top.type[e.b] = d.new_type_2; top.mass[e.b] = d.new_mass_2; top.q[e.b] = d.new_q_2; types_changed = true; }
+        types_changed |= d.new_type_1 >= 0 || d.new_type_2 >= 0;    // (conservative: the force list depends on the types)
       }
     };
+    // the host's type mirrors are needed right now only where the host itself resolves something by type
     bool mirrors_first = top.spawns_tuples() || !nb_rules.empty();
     for (auto& l : top.lists) mirrors_first |= l.by_types != 0;
+    // (otherwise the log is appended further down, while the device rebuilds its tables)
+    if (mirrors_first) { append_event_log(); sync_type_mirrors(); }
+    else for (size_t k = 0; k < hev.size() && !types_changed; ++k) { const chem_reaction_desc& d = reactions[hev[k].r]; types_changed = d.new_type_1 >= 0 || d.new_type_2 >= 0; }
     std::thread mirror_thr;
     std::exception_ptr mirror_err;
-    if (mirrors_first) log_and_mirror();
-    else mirror_thr = std::thread([&] { try { log_and_mirror(); } catch (...) { mirror_err = std::current_exception(); } });
-    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } mirror_join{mirror_thr};   // also on the error paths
     for (auto& e : hev) {
       const chem_reaction_desc& d = reactions[e.r];
       if (d.is_virtual) break;   // bond-forming events were partitioned to the front
@@ -1248,7 +1347,6 @@ template <typename R> struct CtxT : Ctx {
       // same dependency order as below, fully synchronous: graph -> (labels on the thread) -> spawned tuples (types as
       // they are right after the events) -> neighbour property changes -> tables
       label_bonds = newbonds; label_touched.clear(); labels_pending = true;
-      auto& hs = stage_hs; auto& he = stage_he; auto& hp = stage_hp; auto& es = stage_es; auto& el = stage_el;
       top.link_new_bonds(newbonds);
       label_thr = std::thread([this] {
         try { top.merge_new_bonds(label_bonds, label_touched); } catch (...) { label_err = std::current_exception(); }
@@ -1256,12 +1354,8 @@ template <typename R> struct CtxT : Ctx {
       top.spawn_for_new_bonds(newbonds);
       if (label_thr.joinable()) label_thr.join();   // the flood fill reads the graph only; types are not touched by it, but keep it simple
       neighbour_changes();
-      top.build_excl(es, el);
-      top.build_bonded(hs, he, hp);
-      upload_bonded_from(hs, he, hp);
-      excl_start.upload(es, stream); excl_list.upload(el, stream);
-      HIPCHK(hipStreamSynchronize(stream));
-      has_excl = el.empty() ? 0 : 1; excl_dirty = false;
+      upload_excl(false);
+      upload_bonded(false);
       resort = true;
       set_ctl_field(&DevCtl::force_rebuild, 1);
     } else if (!newbonds.empty()) {
@@ -1269,19 +1363,21 @@ template <typename R> struct CtxT : Ctx {
       //   bonded CSR  <- lists            exclusion CSR <- exclusions <- (spawned tuples <- graph)
       //   cluster labels <- graph, read again only by the NEXT reaction scan -> host thread, joined lazily
       label_bonds = newbonds; label_touched.clear(); labels_pending = true;
-      auto& hs = stage_hs; auto& he = stage_he; auto& hp = stage_hp;
-      auto& es = stage_es; auto& el = stage_el;
       if (!top.spawns_tuples()) {
-        std::thread tb([&] { const double tb0 = now_s(); top.build_bonded(hs, he, hp); if (g_trace) fprintf(stderr, "[chem trace] build_bonded (thread) %.3f ms\n", 1e3 * (now_s() - tb0)); });
-        label_thr = std::thread([this] {
-          try { top.link_new_bonds(label_bonds); top.merge_new_bonds(label_bonds, label_touched); } catch (...) { label_err = std::current_exception(); }
+        // the device tables only need the new tuples / pairs: the bond graph, the cluster labels AND the host's own
+        // exclusion rows (read by chem_get_exclusions only) are brought up to date on the thread, beside the MD steps
+        top.excl_log.reserve(top.excl_log.size() + newbonds.size());
+        const size_t log0 = top.excl_log.size();
+        for (auto& e : newbonds) top.excl_log.emplace_back(e.first, e.second);   // (a bond's pair is always new: list_insert deduplicated)
+        label_thr = std::thread([this, log0] {
+          try {
+            top.link_new_bonds(label_bonds); top.merge_new_bonds(label_bonds, label_touched);
+            // rows + pair count; the log already holds these pairs
+            for (auto& e : label_bonds) { if (HostTopology::sorted_insert(top.excl[e.first], e.second)) { HostTopology::sorted_insert(top.excl[e.second], e.first); ++top.n_excl_pairs; } }
+            (void)log0;
+          } catch (...) { label_err = std::current_exception(); }
         });
-        top.exclude_new_bonds(newbonds);
-        trc.lap("exclude");
-        top.build_excl(es, el);
-        trc.lap("build_excl");
-        tb.join();
-        trc.lap("join bonded");
+        trc.lap("threads started");
       } else {
         top.link_new_bonds(newbonds);
         label_thr = std::thread([this] {
@@ -1289,27 +1385,27 @@ template <typename R> struct CtxT : Ctx {
         });
         top.spawn_for_new_bonds(newbonds);
         trc.lap("link+spawn");
-        std::thread tx([&] { top.build_excl(es, el); });
-        top.build_bonded(hs, he, hp);
-        tx.join();
       }
-      upload_bonded_from(hs, he, hp);
-      excl_start.upload(es, stream); excl_list.upload(el, stream);
+      upload_excl(false, false);
+      upload_bonded(false, false);
+      trc.lap("table builds enqueued");
+      if (!mirrors_first) { append_event_log(); trc.lap("event log"); }
       HIPCHK(hipStreamSynchronize(stream));
-      has_excl = el.empty() ? 0 : 1; excl_dirty = false;
       trc.lap("uploads");
       resort = true;
       set_ctl_field(&DevCtl::force_rebuild, 1);
     }
     if (mirror_thr.joinable()) mirror_thr.join();
     if (mirror_err) std::rethrow_exception(mirror_err);
+    if (!mirrors_first && newbonds.empty()) { append_event_log(); trc.lap("event log"); }
     if (newbonds.empty()) neighbour_changes();   // rules on reactions that form no bond
     if (types_changed) { resort = true; set_ctl_field(&DevCtl::force_rebuild, 1); }   // force list depends on types
     if (newbonds.empty() && types_changed) {
       bool any_typed = false;
       for (auto& l : top.lists) any_typed |= l.by_types != 0;
-      if (any_typed) upload_bonded();
+      if (any_typed) upload_bonded(false);     // same tuples, slots re-resolved against the new types
     }
+    trc.lap("end");
     tm.reaction_wall_s += now_s() - t0;
   }
 
@@ -1553,7 +1649,7 @@ int chem_set_particles(chem_ctx* ctx, int64_t n, const int64_t* id, const int32_
   for (int64_t i = 1; i < n; ++i) if (id[i] <= id[i - 1]) { sorted = false; break; }
   if (!sorted) std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return id[a] < id[b]; });
   t.n = n; t.id.resize(n); t.type.resize(n); t.state.resize(n); t.res_id.resize(n); t.mol_id.resize(n); t.mass.resize(n); t.q.resize(n);
-  t.graph.assign(n, TagRow()); t.excl.assign(n, TagRow()); t.n_excl_pairs = 0; t.id2tag.clear();
+  t.graph.assign(n, TagRow()); t.excl.assign(n, TagRow()); t.n_excl_pairs = 0; t.excl_log.clear(); t.id2tag.clear();
   for (auto& l : t.lists) { l.ent.clear(); l.seen.clear(); }
   c.pos0.resize(3 * n); c.vel0.assign(3 * n, 0.0);
   t.contiguous = true; t.id0 = id[order[0]];
@@ -1569,7 +1665,7 @@ int chem_set_particles(chem_ctx* ctx, int64_t n, const int64_t* id, const int32_
   }
   if (!t.contiguous) for (int64_t k = 0; k < n; ++k) t.id2tag[t.id[k]] = (int32_t)k;
   c.particles_dirty = c.pair_dirty = c.bonded_dirty = c.excl_dirty = c.labels_dirty = true; c.resort = true;
-  c.step = 0; c.events.clear(); c.raw_events.clear(); c.n_events = 0;
+  c.step = 0; c.events.clear(); c.arena.clear();
   return 0;
   API_END(ctx)
 }
@@ -1593,7 +1689,7 @@ int chem_set_exclusions(chem_ctx* ctx, int64_t n, const int64_t* p) {
   HostTopology& t = CTX.top;
   REQUIRE(t.n > 0, CHEM_ESTATE, "set particles before exclusions");
   for (auto& r : t.excl) r.clear();
-  t.n_excl_pairs = 0;
+  t.n_excl_pairs = 0; t.excl_log.clear();
   for (int64_t k = 0; k < n; ++k) {
     const int a = t.tag_of(p[2 * k]), b = t.tag_of(p[2 * k + 1]);
     REQUIRE(a >= 0 && b >= 0, CHEM_EINVAL, "exclusion: unknown particle id");
@@ -1811,18 +1907,20 @@ int64_t chem_get_state(chem_ctx* ctx, int what, void* out, int64_t cap) {
 int64_t chem_get_events(chem_ctx* ctx, chem_event* out, int64_t cap) {
   API_BEGIN
   Ctx& c = CTX;
-  const int64_t n = c.n_events;
+  const int64_t n = (int64_t)c.arena.size();
   if (!out) return n;
   REQUIRE(cap >= n, CHEM_ENOSPC, "get_events: capacity");
-  // expand the raw per-step blocks and put each into canonical order: (step, min id, max id)
-  for (auto& blk : c.raw_events) {
-    const size_t m = blk.a.size(), first = c.events.size();
-    for (size_t k = 0; k < m; ++k) c.events.push_back(chem_event{blk.step, c.top.id[blk.a[k]], c.top.id[blk.b[k]], blk.r[k], blk.intra.empty() ? 0 : (int32_t)blk.intra[k], blk.d2[k]});
+  // expand the blocks that are new since the last call, each into canonical order: (step, min id, max id)
+  auto& A = c.arena;
+  for (size_t bi = A.expanded_blocks; bi < A.blocks.size(); ++bi) {
+    const size_t k0 = A.blocks[bi].second, k1 = bi + 1 < A.blocks.size() ? A.blocks[bi + 1].second : A.size(), first = c.events.size();
+    for (size_t k = k0; k < k1; ++k)
+      c.events.push_back(chem_event{A.blocks[bi].first, c.top.id[A.a[k]], c.top.id[A.b[k]], A.r[k], A.intra.size() > k ? (int32_t)A.intra[k] : 0, A.d2[k]});
     std::sort(c.events.begin() + first, c.events.end(), [](const chem_event& p, const chem_event& q) {
       return std::make_pair(std::min(p.id_a, p.id_b), std::max(p.id_a, p.id_b)) < std::make_pair(std::min(q.id_a, q.id_b), std::max(q.id_a, q.id_b));
     });
   }
-  c.raw_events.clear();
+  A.expanded_blocks = A.blocks.size();
   std::copy(c.events.begin(), c.events.end(), out);
   return n;
   API_END(ctx)

@@ -131,11 +131,14 @@ struct HostTopology {
 
   static bool sorted_insert(TagRow& v, int32_t x) { return v.insert(x); }
 
+  // every accepted pair is also appended to excl_log: the device builds its exclusion CSR from that flat,
+  // append-only array (only the tail added since the last upload travels)
+  std::vector<std::pair<int32_t, int32_t>> excl_log;
   bool exclude(int32_t a, int32_t b) {
     if (a == b) return false;
     bool ins = sorted_insert(excl[a], b);
     sorted_insert(excl[b], a);
-    if (ins) ++n_excl_pairs;
+    if (ins) { ++n_excl_pairs; excl_log.emplace_back(a, b); }
     return ins;
   }
 
@@ -258,6 +261,28 @@ struct HostTopology {
       if (type[p] != rl.old_type) continue;
       type[p] = rl.new_type; mass[p] = rl.new_mass; q[p] = rl.new_q;
       out.push_back(PropChange{p, rl.new_type, rl.set_state, rl.new_state, rl.new_mass, rl.new_q});
+    }
+  }
+
+  // parameter slots of the bonded lists and the keys the device resolves them by (md_kernels.hpp SlotKey):
+  // one slot per plain list, one per (typed list, type tuple), in list order
+  struct HSlotKey { int list, t0, t1, t2, t3, by_types, arity, pad; };
+  void build_params(std::vector<HBondedParam>& bpar, std::vector<HSlotKey>& keys) const {
+    bpar.clear(); keys.clear();
+    for (size_t li = 0; li < lists.size(); ++li) {
+      const HostList& l = lists[li];
+      if (!l.by_types) {
+        if (!l.has_plain) continue;
+        HBondedParam bp{l.kind, (int)li, l.arity, 0, {0}};
+        std::copy(l.plain.begin(), l.plain.end(), bp.p);
+        bpar.push_back(bp); keys.push_back(HSlotKey{(int)li, -1, -1, -1, -1, 0, l.arity, 0});
+      } else {
+        for (auto& kv : l.typed) {
+          HBondedParam bp{l.kind, (int)li, l.arity, 0, {0}};
+          std::copy(kv.second.begin(), kv.second.end(), bp.p);
+          bpar.push_back(bp); keys.push_back(HSlotKey{(int)li, kv.first[0], kv.first[1], kv.first[2], kv.first[3], 1, l.arity, 0});
+        }
+      }
     }
   }
 

@@ -1474,20 +1474,22 @@ struct UniLJ { float rc2, lj1, lj2, pad; double drc2, dlj1, dlj2; };   // all li
 // exchange is still in flight on the communication stream, and the two boundary tile layers after it.
 struct TileSub { int base1, n1, base2; };
 
-template <typename R, int TPP, bool ENERGY, int BS, int MODE>
+// DIAG = true: diagnostic instantiation with per-block phase stamps (`dbg`) and early exits (`ablate`: 1 stop after
+// staging, 2 skip staging, 3 descriptor only, 4 dispatch only); the production instantiation carries neither.
+// guard != 0: speculative launch of the decomposed path -- leave at once while a rebuild is pending.
+template <typename R, int TPP, bool ENERGY, int BS, int MODE, bool DIAG = false>
 __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
                                                    const TileLDS<R>* __restrict__ desc, const unsigned short* __restrict__ nl16,
                                                    const int* __restrict__ nnh, int S16,
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
                                                    int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
-                                                   double half_skin, DevCtl* ctl, int ablate, long long* __restrict__ dbg, TileSub sub_) {
+                                                   double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_) {
   constexpr bool LJONLY = MODE >= 1;
   constexpr int NCH = TPP == 1 ? 3 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
-  if (dbg) st0 = wall_clock64();
-  if (ablate == 4) return;   // diagnostic: dispatch cost only
-  if ((ablate & 256) && ctl->need_rebuild) return;   // speculative launch (decomposed path): the host rebuilds first and launches again
-  ablate &= 255;
+  if (DIAG && dbg) st0 = wall_clock64();
+  if (DIAG && ablate == 4) return;   // diagnostic: dispatch cost only
+  if (guard && ctl->need_rebuild) return;   // speculative launch (decomposed path): the host rebuilds first and launches again
   __shared__ TileLDS<R> T;
   __shared__ PairCore<R> spc[kMaxTypes * kMaxTypes];
   CHEM_DYN_LDS(R);
@@ -1499,8 +1501,8 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
   const int tile = vtile < sub_.n1 ? sub_.base1 + vtile : sub_.base2 + (vtile - sub_.n1);
   tile_load_desc<R>(T, desc, tile);
   __syncthreads();
-  if (ablate == 3) return;   // diagnostic: descriptor load only
-  if (dbg) st1 = wall_clock64();
+  if (DIAG && ablate == 3) return;   // diagnostic: descriptor load only
+  if (DIAG && dbg) st1 = wall_clock64();
   const int nhome = T.geom[4], hbase = T.geom[5];
   const int slice = threadIdx.x / TPP, sub = threadIdx.x % TPP;
   constexpr int NSL = BS / TPP;
@@ -1523,10 +1525,10 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
       pkv[c] = (sub + c * TPP) * 8 < S16 ? nt_load_u4(&reg[(size_t)(sub + c * TPP) * nhome + q]) : make_uint4(0, 0, 0, 0);
   };
   if (slice < nhome) locate(slice);
-  if (ablate != 2) tile_fill<R, BS>(T, sx, CAP, x4, 0);
+  if (!DIAG || ablate != 2) tile_fill<R, BS>(T, sx, CAP, x4, 0);
   __syncthreads();
-  if (ablate == 1) return;   // diagnostic: staging only
-  if (dbg) st2 = wall_clock64();
+  if (DIAG && ablate == 1) return;   // diagnostic: staging only
+  if (DIAG && dbg) st2 = wall_clock64();
   double e_lj = 0, e_tab = 0, vir = 0;
   for (int q0 = 0; q0 < nhome; q0 += NSL) {
     const int q = q0 + slice;
@@ -1569,7 +1571,7 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
     }
     if (p >= 0 && sub == 0) f4[p] = mk4<R>(fx, fy, fz, (R)0);
   }
-  if (dbg && threadIdx.x == 0) {   // diagnostic build path only: per-block phase stamps (100 MHz wall clock)
+  if (DIAG && dbg && threadIdx.x == 0) {   // diagnostic instantiation only: per-block phase stamps (100 MHz wall clock)
     st3 = wall_clock64();
     long long* o = dbg + 6 * (size_t)blockIdx.x;
     o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = 0; o[5] = tile;
@@ -2267,7 +2269,8 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
                                                             const TileLDS<R>* __restrict__ desc, const int* __restrict__ state,
                                                             const int* __restrict__ res_id, const int* __restrict__ mol_id, BoxD box,
                                                             const ReactSet* __restrict__ rs_g, Candidate* __restrict__ region, int region_cap,
-                                                            int* __restrict__ tile_count, DevCtl* ctl) {
+                                                            int* __restrict__ tile_count, DevCtl* ctl, R slack,
+                                                            const int* __restrict__ excl_start, const int* __restrict__ excl_list) {
   __shared__ TileLDS<R> T;
   __shared__ ReactSet rs;
   __shared__ int s_cnt;
@@ -2313,12 +2316,35 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
       }
       if (!any) continue;
       const Vec4<R> xgi = x4[p];
+      // x-window of every stencil row, as in the list build (dev_nlist_tile) but for the largest reaction radius and
+      // with the tables of the LAST rebuild: a candidate sits within `slack` (= skin/2) of where it was binned, so the
+      // row distances shrink and the window grows by that much
+      const R rmax = sqrt_r(maxcut2), weps = T.clen[0] * (R)2e-4;
+      auto suboff = [&](int r, int f, bool lower) {
+        const int k = f >> 2, j = f & 3;
+        const int base = T.celloff[r][k];
+        if (j == 0) return base;
+        const int pk = T.cellsub[r][k];
+        if (pk < 0) return lower ? base : T.celloff[r][k + 1];
+        return base + ((pk >> (8 * (j - 1))) & 0xff);
+      };
 #pragma unroll 1
       for (int dzy = 0; dzy < 9; ++dzy) {
         const int dz = dzy / 3, dy = dzy - 3 * dz;
         const int r = (lz + dz) * SY + (ly + dy);
-        const int a = T.rowoff[r] + T.celloff[r][lx];
-        int b = T.rowoff[r] + T.celloff[r][lx + 3];
+        const R ylo = T.org[1] + (R)(ly + 1) * T.clen[1], zlo = T.org[2] + (R)(lz + 1) * T.clen[2];
+        R ddy = dy == 0 ? xi.y - ylo : (dy == 2 ? ylo + T.clen[1] - xi.y : (R)0);
+        R ddz = dz == 0 ? xi.z - zlo : (dz == 2 ? zlo + T.clen[2] - xi.z : (R)0);
+        ddy -= slack + weps; ddz -= slack + weps;
+        ddy = ddy > 0 ? ddy : (R)0; ddz = ddz > 0 ? ddz : (R)0;
+        const R w2 = rmax * rmax - ddy * ddy - ddz * ddz;
+        if (w2 < (R)0) continue;
+        const R ws = (sqrt_r(w2) + slack + weps) * T.subinv, sxi = (xi.x - T.org[0]) * T.subinv;
+        int f_lo = (int)(sxi - ws), f_hi = (int)(sxi + ws);
+        f_lo = f_lo > lx * NSUB ? f_lo : lx * NSUB;
+        f_hi = f_hi < (lx + 3) * NSUB - 1 ? f_hi : (lx + 3) * NSUB - 1;
+        const int a = T.rowoff[r] + suboff(r, f_lo, true);
+        int b = T.rowoff[r] + suboff(r, f_hi + 1, false);
         b = b < total ? b : total;
         for (int sl = a; sl < b; ++sl) {
           const Vec4<R> xj = sx[sl];
@@ -2327,6 +2353,11 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
           const int jw = real_as_idx(xj.w), j = jw >> 5, tj = jw & 15;
           const int tgj = tag[j];
           if (!(tgi < tgj)) continue;          // every pair once, from its lower tag (on the rank that owns it)
+          if (excl_start) {                    // candidates are Verlet-list pairs: an excluded (e.g. bonded) pair never reacts
+            bool ex = false;
+            for (int e = excl_start[tgi]; e < excl_start[tgi + 1]; ++e) ex |= excl_list[e] == tgj;
+            if (ex) continue;
+          }
           const int sj = state[tgj], rj = res_id[tgj], mj = mol_id[tgj];
           const D3 d = minimgD(box, posD<R>(xgi) - posD<R>(x4[j]));
           const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(d.x, d.x), __dmul_rn(d.y, d.y)), __dmul_rn(d.z, d.z));
@@ -2476,6 +2507,161 @@ __global__ void k_apply_props(int nchg, const PropChangeDev* __restrict__ chg, i
   if (c.set_state) state[c.tag] = c.state;
   const int i = rtag[c.tag];
   if (i >= 0) { x4[i].w = (R)c.type; v4[i].w = (R)c.mass; }
+}
+
+// =======================================================================================
+// Per-tag CSR tables (bonded entries, exclusions) built ON THE DEVICE from flat, append-only arrays.
+// A bond-forming reaction step used to rebuild both tables on the host (a pass over all 10^6 rows, ~14 MB of
+// uploads, 3-4 ms); now the host uploads only the NEW tuples / pairs and four small kernels rebuild the CSR:
+// count (atomics by tag) -> exclusive scan -> fill (atomic cursor) -> canonical order inside every row
+// (one thread per tag, insertion sort: rows hold a handful of entries).  The row order is a pure function of
+// the flat arrays, so the tables -- and with them the force sums -- are run-to-run deterministic.
+// =======================================================================================
+// exclusive scan of n counters -> start[0..n] in three launches (4096 counters per block; block totals scanned by one
+// block; offsets added); the counters are cleared on the way (they become the fill cursors)
+constexpr int kScanItems = 4096;
+__global__ __launch_bounds__(1024) void k_scan_local(int n, int* __restrict__ cnt, int* __restrict__ start, int* __restrict__ btot) {
+  __shared__ int ws[16];
+  const int i0 = blockIdx.x * kScanItems + threadIdx.x * 4;
+  int v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[k] = 0; if (i0 + k < n) { v[k] = cnt[i0 + k]; cnt[i0 + k] = 0; } }
+  const int sum = v[0] + v[1] + v[2] + v[3];
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  if (lane == 63) ws[w] = incl;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { if (k < w) off += ws[k]; tot += ws[k]; }
+  int run = off + incl - sum;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (i0 + k < n) start[i0 + k] = run; run += v[k]; }
+  if (threadIdx.x == 0) btot[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(1024) void k_scan_blocks(int nb, int* __restrict__ btot, int n, int* __restrict__ start) {
+  __shared__ int ws[16];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  const int lane = lane_id(), w = threadIdx.x >> 6;
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? btot[i] : 0;
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    if (lane == 63) ws[w] = incl;
+    __syncthreads();
+    int off = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) { if (k < w) off += ws[k]; tot += ws[k]; }
+    if (i < nb) btot[i] = carry_s + off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) start[n] = carry_s;
+}
+__global__ __launch_bounds__(1024) void k_scan_add(int n, const int* __restrict__ btot, int* __restrict__ start) {
+  const int off = btot[blockIdx.x];
+  if (off == 0) return;
+  const int i0 = blockIdx.x * kScanItems + threadIdx.x * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (i0 + k < n) start[i0 + k] += off;
+}
+
+// ---- exclusions: flat pairs (a, b) -> symmetric CSR, rows ascending (= HostTopology::build_excl) ----
+__global__ void k_ex_count(int m, const int2* __restrict__ pairs, int* __restrict__ cnt) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const int2 p = pairs[k];
+  atomicAdd(&cnt[p.x], 1); atomicAdd(&cnt[p.y], 1);
+}
+__global__ void k_ex_fill(int m, const int2* __restrict__ pairs, const int* __restrict__ start, int* __restrict__ cursor, int* __restrict__ list) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const int2 p = pairs[k];
+  list[start[p.x] + atomicAdd(&cursor[p.x], 1)] = p.y;
+  list[start[p.y] + atomicAdd(&cursor[p.y], 1)] = p.x;
+}
+__global__ void k_ex_sort(int n, const int* __restrict__ start, int* __restrict__ cursor, int* __restrict__ list) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  cursor[t] = 0;
+  const int s = start[t], e = start[t + 1];
+  for (int i = s + 1; i < e; ++i) {
+    const int v = list[i];
+    int j = i - 1;
+    while (j >= s && list[j] > v) { list[j + 1] = list[j]; --j; }
+    list[j + 1] = v;
+  }
+}
+
+// ---- bonded entries: flat tuples (tags t0..t3, list index) -> per-tag CSR of BondedEntry ----
+// parameter slot of a tuple: plain lists have one slot, typed lists one per registered type tuple (matched forwards
+// or backwards against the CURRENT particle types); -1 = no parameters for these types (tuple skipped, as
+// HostTopology::build_bonded does)
+struct SlotKey { int list, t0, t1, t2, t3, by_types, arity, pad; };
+template <typename R>
+__global__ void k_bt_count(int ne, const int4* __restrict__ fent, const int* __restrict__ flist, int nslot, const SlotKey* __restrict__ keys,
+                           const Vec4<R>* __restrict__ x4, const int* __restrict__ rtag, const int* __restrict__ type_by_tag,
+                           int* __restrict__ eslot, int* __restrict__ cnt) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const int4 tt = fent[e];
+  const int li = flist[e];
+  const int tg[4] = {tt.x, tt.y, tt.z, tt.w};
+  int slot = -1, arity = 2;
+  for (int s = 0; s < nslot && slot < 0; ++s) {
+    const SlotKey k = keys[s];
+    if (k.list != li) continue;
+    arity = k.arity;
+    if (!k.by_types) { slot = s; break; }
+    int ty[4] = {-1, -1, -1, -1};
+    for (int q = 0; q < k.arity; ++q) {
+      if (type_by_tag) ty[q] = type_by_tag[tg[q]];
+      else { const int i = rtag[tg[q]]; ty[q] = i >= 0 ? (int)x4[i].w : -1; }
+    }
+    const int kt[4] = {k.t0, k.t1, k.t2, k.t3};
+    bool fwd = true, rev = true;
+    for (int q = 0; q < k.arity; ++q) { fwd &= ty[q] == kt[q]; rev &= ty[k.arity - 1 - q] == kt[q]; }
+    if (fwd || rev) slot = s;
+  }
+  eslot[e] = slot;
+  if (slot < 0) return;
+  const int w = arity == 4 ? 2 : 1;
+  for (int q = 0; q < arity; ++q) atomicAdd(&cnt[tg[q]], w);
+}
+__global__ void k_bt_fill(int ne, const int4* __restrict__ fent, const int* __restrict__ eslot, const SlotKey* __restrict__ keys,
+                          const int* __restrict__ start, int* __restrict__ cursor, BondedEntry* __restrict__ bent, int* __restrict__ bkey) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ne) return;
+  const int slot = eslot[e];
+  if (slot < 0) return;
+  const int4 tt = fent[e];
+  const int arity = keys[slot].arity, w = arity == 4 ? 2 : 1;
+  const int tg[4] = {tt.x, tt.y, tt.z, tt.w};
+  for (int q = 0; q < arity; ++q) {
+    const int pos = start[tg[q]] + atomicAdd(&cursor[tg[q]], w);
+    bent[pos] = BondedEntry{tt.x, tt.y, arity > 2 ? tt.z : 0, slot | (q << 28)};
+    bkey[pos] = 2 * e;
+    if (arity == 4) { bent[pos + 1] = BondedEntry{tt.w, 0, 0, 0}; bkey[pos + 1] = 2 * e + 1; }
+  }
+}
+// rows in flat-array order (key = 2 e + half); counts[0] = tags that own entries
+__global__ void k_bt_sort(int n, const int* __restrict__ start, int* __restrict__ cursor, BondedEntry* __restrict__ bent, int* __restrict__ bkey, int* __restrict__ counts) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  cursor[t] = 0;
+  const int s = start[t], e = start[t + 1];
+  if (e > s) atomicAdd(&counts[0], 1);
+  for (int i = s + 1; i < e; ++i) {
+    const int kv = bkey[i]; const BondedEntry bv = bent[i];
+    int j = i - 1;
+    while (j >= s && bkey[j] > kv) { bkey[j + 1] = bkey[j]; bent[j + 1] = bent[j]; --j; }
+    bkey[j + 1] = kv; bent[j + 1] = bv;
+  }
 }
 
 template <typename T> __global__ void k_fill(T* p, T v, size_t n) {

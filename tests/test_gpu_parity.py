@@ -1023,3 +1023,23 @@ def test_destroying_a_decomposed_context_with_work_in_flight(make_oracle):
     e.run(3)
     assert np.isfinite(e.get_state("FORCE")).all()
     e.close()
+
+
+@pytest.mark.gpu
+def test_excluded_pairs_are_not_reaction_candidates(make_gpu, make_oracle):
+    """Candidates are pairs of the Verlet list (reaction_setup.py:416: ChemicalReaction(system, vl, ...)): a pair that is
+    excluded from it -- here: already bonded -- never reacts, even while its types and states still fit a reaction."""
+    spec = W.reactive_melt(n=8788, seed=17, interval=5)
+    for r in spec["reaction"]["reactions"]:          # state windows that stay open after an event: re-reaction possible
+        r["min_state_1"], r["max_state_1"], r["min_state_2"], r["max_state_2"], r["delta_1"], r["delta_2"] = 0, 100, 0, 100, 0, 0
+        r["is_virtual"] = False
+        r.pop("new_type_2", None)
+        r["intramolecular"] = True
+    g, o, h = both(make_gpu, make_oracle, spec, 64)
+    g.run(20); o.run(20)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 1000
+    assert [e[:4] for e in eg] == [e[:4] for e in eo]
+    pairs = [(min(e[1], e[2]), max(e[1], e[2])) for e in eo]
+    assert len(pairs) == len(set(pairs))             # no pair reacted twice
+    assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
