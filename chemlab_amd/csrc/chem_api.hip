@@ -104,6 +104,16 @@ struct Ctx {
     void clear() { a.clear(); b.clear(); r.clear(); d2.clear(); intra.clear(); blocks.clear(); mirror_pos = 0; expanded_blocks = 0; }
   } arena;
   int opt_intra_inter = 0;   // classify every event as intra-/inter-cluster at event time (ar.save_intra_inter_counter)
+  // records of one reaction step (device order) -> arena; runs on the bookkeeping thread beside the MD steps unless the
+  // host needs the type mirrors within the reaction step itself
+  template <class Rec> void append_events(const Rec* ev, size_t m, int64_t at_step, const std::vector<int8_t>& intra_flags) {
+    EventArena& A = arena;
+    const size_t n0 = A.size();
+    A.blocks.emplace_back(at_step, n0);
+    A.a.resize(n0 + m); A.b.resize(n0 + m); A.r.resize(n0 + m); A.d2.resize(n0 + m);
+    if (!intra_flags.empty()) { A.intra.resize(n0 + m); std::copy(intra_flags.begin(), intra_flags.end(), A.intra.begin() + n0); }
+    for (size_t k = 0; k < m; ++k) { A.a[n0 + k] = ev[k].a; A.b[n0 + k] = ev[k].b; A.r[n0 + k] = ev[k].r; A.d2[n0 + k] = ev[k].d2; }
+  }
   void sync_type_mirrors() {
     for (size_t k = arena.mirror_pos; k < arena.size(); ++k) {
       const chem_reaction_desc& d = reactions[arena.r[k]];
@@ -176,7 +186,12 @@ template <typename R> struct CtxT : Ctx {
   std::thread label_thr; bool labels_pending = false; std::exception_ptr label_err;
   std::vector<std::pair<int32_t, int32_t>> label_bonds; std::vector<int32_t> label_touched;
   void join_async() override {
+    join_thread();
     sync_type_mirrors();      // any API call other than chem_run sees current type/mass/charge mirrors
+  }
+  // the bookkeeping thread of the last reaction step (event log, bond graph, cluster labels, exclusion rows); the
+  // reaction step itself joins only this -- replaying the type mirrors there would cost the 2-3 ms it just saved
+  void join_thread() {
     if (label_thr.joinable()) label_thr.join();
     if (label_err) { std::exception_ptr e = label_err; label_err = nullptr; labels_pending = false; std::rethrow_exception(e); }
     if (labels_pending) {
@@ -538,7 +553,8 @@ template <typename R> struct CtxT : Ctx {
   // the table sizes the host needs (entry and owner counts) are upper bounds from the flat arrays, the kernels
   // themselves read the exact figures from device memory
   size_t fent_members = 0;     // sum of arity * (2 for quadruples) over the flat tuples
-  std::vector<HBondedParam> stage_hp; std::vector<HostTopology::HSlotKey> stage_hk; std::vector<int4> stage_ne; std::vector<int> stage_nl;
+  std::vector<HBondedParam> stage_hp; std::vector<HostTopology::HSlotKey> stage_hk;
+  PinnedVec<int4> stage_ne; PinnedVec<int> stage_nl; PinnedVec<int2> stage_ep;   // pinned: a pageable async copy blocks for ~0.1 ms
   void upload_bonded(bool full = true, bool wait = true) {
     upload_bond_tables();
     // (host staging lives in members: with wait = false the copies may still be in flight when this returns)
@@ -552,7 +568,7 @@ template <typename R> struct CtxT : Ctx {
       HIPCHK(hipMemcpyAsync(skeys.p, hk.data(), hk.size() * sizeof(SlotKey), hipMemcpyHostToDevice, stream));
     }
     if (full || list_uploaded.size() != top.lists.size()) { fent_n = 0; fent_members = 0; list_uploaded.assign(top.lists.size(), 0); }
-    std::vector<int4>& ne = stage_ne; std::vector<int>& nl = stage_nl;
+    PinnedVec<int4>& ne = stage_ne; PinnedVec<int>& nl = stage_nl;
     ne.clear(); nl.clear();
     bool typed = false;
     for (size_t li = 0; li < top.lists.size(); ++li) {
@@ -580,7 +596,8 @@ template <typename R> struct CtxT : Ctx {
     const size_t ub = (fent_n && nslot) ? fent_members : 0;      // upper bound of the entry count (tuples without parameters drop out)
     if (ub) {
       const int ne_i = (int)fent_n;
-      eslot.alloc(fent_n); bent.alloc(ub); bkey.alloc(ub);
+      if (eslot.n < fent_n) eslot.alloc(fent_n + fent_n / 2 + 1024);          // (amortised: these grow at every reaction step)
+      if (bent.n < ub) { bent.alloc(ub + ub / 2 + 1024); bkey.alloc(ub + ub / 2 + 1024); }
       hipLaunchKernelGGL((k_bt_count<R>), dim3(cdiv(ne_i, 256)), dim3(256), 0, stream, ne_i, fent.p, flist.p, nslot, skeys.p, x4.p, rtag.p,
                          typed ? (const int*)type_tag.p : (const int*)nullptr, eslot.p, tcnt.p);
       scan_counts(nt, tcnt.p, bstart.p);
@@ -588,7 +605,8 @@ template <typename R> struct CtxT : Ctx {
       hipLaunchKernelGGL(k_bt_sort, dim3(cdiv(nt, 256)), dim3(256), 0, stream, nt, bstart.p, tcnt.p, bent.p, bkey.p, tcounts.p);
     } else HIPCHK(hipMemsetAsync(bstart.p, 0, sizeof(int) * ((size_t)nt + 1), stream));
     nbent = (int64_t)ub; nb_owner = (int)std::min<size_t>((size_t)nt, ub);
-    bwork.alloc(std::max(nb_owner, 1)); bj.alloc(std::max<size_t>((size_t)nbent, 1));
+    if (bwork.n < (size_t)std::max(nb_owner, 1)) bwork.alloc((size_t)nb_owner + nb_owner / 2 + 1024);
+    if (bj.n < (size_t)std::max<int64_t>(nbent, 1)) bj.alloc((size_t)nbent + nbent / 2 + 1024);
     bwork_dirty = true;
     bonded_dirty = false;
     if (wait) HIPCHK(hipStreamSynchronize(stream));
@@ -600,11 +618,16 @@ template <typename R> struct CtxT : Ctx {
     const size_t add = have - epairs_n;
     grow(epairs, epairs_n, have, stream);
     static_assert(sizeof(std::pair<int32_t, int32_t>) == sizeof(int2), "layout");
-    if (add) HIPCHK(hipMemcpyAsync(epairs.p + epairs_n, top.excl_log.data() + epairs_n, add * sizeof(int2), hipMemcpyHostToDevice, stream));
+    if (add) {
+      stage_ep.resize(add);
+      std::memcpy(stage_ep.data(), top.excl_log.data() + epairs_n, add * sizeof(int2));
+      HIPCHK(hipMemcpyAsync(epairs.p + epairs_n, stage_ep.data(), add * sizeof(int2), hipMemcpyHostToDevice, stream));
+    }
     epairs_n = have;
     const int nt = nglob > 0 ? nglob : (int)top.n;
     if (tcnt.n < (size_t)nt + 1) { tcnt.alloc((size_t)nt + 1); HIPCHK(hipMemsetAsync(tcnt.p, 0, sizeof(int) * ((size_t)nt + 1), stream)); }
-    excl_start.alloc((size_t)nt + 1); excl_list.alloc(std::max<size_t>(2 * have, 1));
+    excl_start.alloc((size_t)nt + 1);
+    if (excl_list.n < std::max<size_t>(2 * have, 1)) excl_list.alloc(3 * have + 1024);
     if (have) {
       const int m = (int)have;
       hipLaunchKernelGGL(k_ex_count, dim3(cdiv(m, 256)), dim3(256), 0, stream, m, epairs.p, tcnt.p);
@@ -1129,7 +1152,7 @@ template <typename R> struct CtxT : Ctx {
     // reaction_wall_s measures the reaction step, not the MD steps queued before it
     HIPCHK(hipStreamSynchronize(stream));
     const double t0 = now_s();
-    join_async();   // labels of the previous reaction step must be on the device before the scan
+    join_thread();   // labels of the previous reaction step must be on the device before the scan
     alloc_reaction_buffers();
     ReactSet rs{};
     rs.n = (int)reactions.size(); rs.seed = react_seed; rs.step = (uint64_t)step; rs.nearest = nearest;
@@ -1294,30 +1317,24 @@ template <typename R> struct CtxT : Ctx {
       for (size_t k = 0; k < hev.size(); ++k) intra_flags[k] = top.mol_id[hev[k].a] == top.mol_id[hev[k].b] ? 1 : 0;
     }
     // event log: appended to the arena in device order (canonical order is established lazily by chem_get_events)
-    auto append_event_log = [&] {
-      EventArena& A = arena;
-      const size_t n0 = A.size(), m = hev.size();
-      A.blocks.emplace_back(step, n0);
-      A.a.resize(n0 + m); A.b.resize(n0 + m); A.r.resize(n0 + m); A.d2.resize(n0 + m);
-      if (opt_intra_inter) { A.intra.resize(n0 + m); std::copy(intra_flags.begin(), intra_flags.end(), A.intra.begin() + n0); }
-      for (size_t k = 0; k < m; ++k) {
-        const Candidate& e = hev[k];
-        A.a[n0 + k] = e.a; A.b[n0 + k] = e.b; A.r[n0 + k] = e.r; A.d2[n0 + k] = e.d2;
-        const chem_reaction_desc& d = reactions[e.r];
-        types_changed |= d.new_type_1 >= 0 || d.new_type_2 >= 0;    // (conservative: the force list depends on the types)
-      }
-    };
+    for (size_t k = 0; k < hev.size() && !types_changed; ++k) { const chem_reaction_desc& d = reactions[hev[k].r]; types_changed = d.new_type_1 >= 0 || d.new_type_2 >= 0; }   // (conservative: the force list depends on the types)
     // the host's type mirrors are needed right now only where the host itself resolves something by type
     bool mirrors_first = top.spawns_tuples() || !nb_rules.empty();
     for (auto& l : top.lists) mirrors_first |= l.by_types != 0;
     // (otherwise the log is appended further down, while the device rebuilds its tables)
-    if (mirrors_first) { append_event_log(); sync_type_mirrors(); }
-    else for (size_t k = 0; k < hev.size() && !types_changed; ++k) { const chem_reaction_desc& d = reactions[hev[k].r]; types_changed = d.new_type_1 >= 0 || d.new_type_2 >= 0; }
+    if (mirrors_first) { append_events(hev.data(), hev.size(), step, intra_flags); sync_type_mirrors(); }
+    const Candidate* log_ev = hev.data(); const size_t log_n = mirrors_first ? 0 : hev.size(); const int64_t log_step = step;   // what the thread still has to log
+    // (pin_ev is not touched again before the next reaction step, which joins the thread first)
     std::thread mirror_thr;
     std::exception_ptr mirror_err;
-    for (auto& e : hev) {
+    for (size_t k = 0; k < hev.size(); ++k) {
+      const Candidate& e = hev[k];
       const chem_reaction_desc& d = reactions[e.r];
       if (d.is_virtual) break;   // bond-forming events were partitioned to the front
+      if (k + 8 < hev.size() && !reactions[hev[k + 8].r].is_virtual) {   // the de-duplication set is a 10^5-entry hash table: hide its misses
+        int32_t tp[2] = {hev[k + 8].a, hev[k + 8].b};
+        top.lists[reactions[hev[k + 8].r].bond_list].seen.prefetch(tuple_key(tp, 2));
+      }
       int32_t t[2] = {e.a, e.b};
       if (top.list_insert(top.lists[d.bond_list], t)) newbonds.emplace_back(e.a, e.b);
     }
@@ -1369,8 +1386,9 @@ template <typename R> struct CtxT : Ctx {
         top.excl_log.reserve(top.excl_log.size() + newbonds.size());
         const size_t log0 = top.excl_log.size();
         for (auto& e : newbonds) top.excl_log.emplace_back(e.first, e.second);   // (a bond's pair is always new: list_insert deduplicated)
-        label_thr = std::thread([this, log0] {
+        label_thr = std::thread([this, log0, log_ev, log_n, log_step, intra_flags] {
           try {
+            if (log_n) append_events(log_ev, log_n, log_step, intra_flags);
             top.link_new_bonds(label_bonds); top.merge_new_bonds(label_bonds, label_touched);
             // rows + pair count; the log already holds these pairs
             for (auto& e : label_bonds) { if (HostTopology::sorted_insert(top.excl[e.first], e.second)) { HostTopology::sorted_insert(top.excl[e.second], e.first); ++top.n_excl_pairs; } }
@@ -1389,7 +1407,6 @@ template <typename R> struct CtxT : Ctx {
       upload_excl(false, false);
       upload_bonded(false, false);
       trc.lap("table builds enqueued");
-      if (!mirrors_first) { append_event_log(); trc.lap("event log"); }
       HIPCHK(hipStreamSynchronize(stream));
       trc.lap("uploads");
       resort = true;
@@ -1397,7 +1414,11 @@ template <typename R> struct CtxT : Ctx {
     }
     if (mirror_thr.joinable()) mirror_thr.join();
     if (mirror_err) std::rethrow_exception(mirror_err);
-    if (!mirrors_first && newbonds.empty()) { append_event_log(); trc.lap("event log"); }
+    if (log_n && newbonds.empty()) {     // no bonds, no label work: the thread only writes the log
+      label_thr = std::thread([this, log_ev, log_n, log_step, intra_flags] {
+        try { append_events(log_ev, log_n, log_step, intra_flags); } catch (...) { label_err = std::current_exception(); }
+      });
+    }
     if (newbonds.empty()) neighbour_changes();   // rules on reactions that form no bond
     if (types_changed) { resort = true; set_ctl_field(&DevCtl::force_rebuild, 1); }   // force list depends on types
     if (newbonds.empty() && types_changed) {

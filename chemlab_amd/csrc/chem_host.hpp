@@ -56,6 +56,7 @@ struct TupleSet {
     slot.assign(old.empty() ? 1024 : old.size() * 2, TupleKey{~0ull, ~0ull}); used = 0;
     for (auto& k : old) if (!empty_key(k)) insert(k);
   }
+  void prefetch(const TupleKey& k) const { if (!slot.empty()) __builtin_prefetch(&slot[TupleKeyHash()(k) & (slot.size() - 1)]); }
   bool insert(const TupleKey& k) {
     if ((used + 1) * 10 >= slot.size() * 7) grow();
     size_t m = slot.size() - 1, i = TupleKeyHash()(k) & m;
