@@ -13,7 +13,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libchem_mi355.so")
+LIB_PATH = os.environ.get("CHEM_MI355_LIB") or os.path.join(HERE, "csrc", "libchem_mi355.so")   # override: A/B builds of the same source (tools/)
 
 CHEM_MAX_LISTS = 32
 CHEM_MAX_TYPES = 16

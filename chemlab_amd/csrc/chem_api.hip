@@ -131,6 +131,8 @@ struct Ctx {
   int opt_time_pair = 0;    // HIP-event timing of every N-th pair-force launch (0 = off)
   int64_t pair_launch_no = 0;
   int opt_fuse = 1;         // fused integrate2+integrate1
+  int opt_fuse_pair = 0;
+  int opt_ablate_list = 0;  // diagnostics (with debug_stamps): parts of the list build left out, see tools/rebuild_stamps.py    // ... and both in the force kernel's epilogue (k_pair_tiles INTEG)
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
   int opt_fused = 1;        // rebuild chain as one persistent launch with grid barriers (single domain, tiles)
   int pair_guard = 0;       // 256 while the force kernels are launched speculatively (decomposed path)
@@ -155,6 +157,8 @@ struct Ctx {
   virtual void set_pair_bs(int) {}
   virtual int64_t debug_dump(long long*, int64_t) { return 0; }
   virtual void debug_enable(int) {}
+  virtual int64_t debug_dump_rebuild(long long*, int64_t) { return 0; }
+  virtual int64_t debug_force_list(int, int32_t*, int64_t) { return -1; }
   virtual void join_async() {}
 };
 
@@ -165,6 +169,8 @@ template <typename R> struct CtxT : Ctx {
   bool state_mirror_stale = false;   // top.state lags the device after reaction steps
   int tile_cap = 0;       // LDS slots of one staged tile (dynamic LDS)
   size_t tile_lds_bytes() const { return (size_t)(tile_cap + 5) * sizeof(V4) + 16; }
+  // the list build has its own layout of the same block (fp32: SoA groups + type masks + slice boundaries)
+  size_t list_lds_need() const { return sizeof(R) == 4 ? std::max(tile_lds_bytes(), list_lds_bytes(tile_cap, kMaxTypes)) : tile_lds_bytes(); }
   hipStream_t stream = nullptr;
   int n = 0;
   DBuf<V4> x4, v4, f4, x4o, v4o, tab, x0;
@@ -179,7 +185,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> nlist, nn, nnh;
   DBuf<unsigned short> nl16;
   DBuf<TileLDS<R>> tdesc;
-  DBuf<long long> dbgbuf; bool dbg_on = false;
+  DBuf<long long> dbgbuf, wgst; bool dbg_on = false;
   Candidate* pin_ev = nullptr; size_t pin_ev_cap = 0;   // pinned host staging for reaction events
   // cluster labels of a reaction step are merged on a host thread beside the following MD steps;
   // joined (and uploaded) before the next reaction scan and before any other API call
@@ -222,6 +228,8 @@ template <typename R> struct CtxT : Ctx {
   DBuf<PairCore<R>> pcore; DBuf<PairExt<R>> pext;
   DBuf<DevCtl> ctl;
   DBuf<unsigned long long> blockmax;
+  DBuf<V4> x4n, fbond;      // second position buffer / bonded forces of the step (integrating force kernel)
+  int maxima_n = 0;         // entries of blockmax the last drift wrote (k_integrate blocks, or tiles)
   DBuf<double> eout, ekout, elist;
   // reactions
   DBuf<Candidate> cand, evout; int cand_cap = 0;
@@ -298,6 +306,7 @@ template <typename R> struct CtxT : Ctx {
       tile_cap = std::max(1024, (need + 255) / 256 * 256);
       const size_t max_lds = 150 * 1024;
       if (tile_lds_bytes() > max_lds) use_tiles = false;   // cells too crowded: per-cell kernels
+
       else set_tile_lds_attr();
     }
     ntiles = use_tiles ? ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY) * (((dd_on ? ncz : box.nc[2]) + HZ - 1) / HZ) : 0;
@@ -313,9 +322,9 @@ template <typename R> struct CtxT : Ctx {
     use_fused = false;
     if (!opt_fused || !use_tiles || dd_on) return;
     const void* fn = reinterpret_cast<const void*>(&k_rebuild_fused<R, 512>);
-    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tile_lds_bytes()));
+    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()));
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, tile_lds_bytes()) != hipSuccess || per_cu < 1) return;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, list_lds_need()) != hipSuccess || per_cu < 1) return;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     int g = std::min(per_cu * prop.multiProcessorCount, 1024) / 8 * 8;
@@ -338,7 +347,7 @@ template <typename R> struct CtxT : Ctx {
   void launch_rebuild_fused() {
     FusedArgs<R> a{};
     a.n = n; a.ncell = box.ncell; a.ntiles = ntiles; a.CAP = tile_cap; a.S = S; a.has_excl = has_excl; a.criterion = opt_criterion;
-    a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = cdiv(n, kIntPerBlock); a.want32 = want32 ? 1 : 0;
+    a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = maxima_n; a.want32 = want32 ? 1 : 0; a.ntypes = ntypes; a.ablate = dbg_on ? opt_ablate_list : 0;
     a.half_skin = 0.5 * skin; a.rl2 = (R)((rc + skin) * (rc + skin));
     a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
@@ -346,20 +355,22 @@ template <typename R> struct CtxT : Ctx {
     a.cell_sub = cell_sub.p; a.cell_n = cell_n.p; a.bucket = bucket.p; a.bcap = bcap; a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
     a.desc = tdesc.p; a.excl_start = excl_start.p; a.excl_list = excl_list.p; a.nl16 = nl16.p; a.nnh = nnh.p; a.nlist = nlist.p; a.nn = nn.p;
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
+    a.wgst = dbg_on && wgst.p ? wgst.p : nullptr;
     a.bstart = bstart.p; a.bent = bent.p; a.bwork = bwork.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
-    hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), tile_lds_bytes(), stream, a);
+    hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), list_lds_need(), stream, a);
     fused_par ^= 1;
   }
 
   void set_tile_lds_attr() {
     const int bytes = (int)tile_lds_bytes();
 #define SETA(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
-    SETA((k_nlist_tiles<R, 512>));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nlist_tiles<R, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()));
     SETA((k_react_scan_tiles<R, 512>));
 #define SETB(T, E, M) SETA((k_pair_tiles<R, T, E, 256, M>)); SETA((k_pair_tiles<R, T, E, 512, M>)); SETA((k_pair_tiles<R, T, E, 1024, M>)); \
                       if (T == 1 && !E) SETA((k_pair_tiles<R, 1, false, 512, M, true>))
 #define SETT(E, M) SETB(1, E, M); SETB(2, E, M); SETB(4, E, M); SETB(8, E, M)
     SETT(false, 2); SETT(false, 1); SETT(false, 0); SETT(true, 0);
+    SETA((k_pair_tiles<R, 1, false, 512, 2, false, true>)); SETA((k_pair_tiles<R, 1, false, 512, 1, false, true>)); SETA((k_pair_tiles<R, 1, false, 512, 0, false, true>));
 #undef SETT
 #undef SETB
 #undef SETA
@@ -422,6 +433,9 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipMemsetAsync(nn.p, 0, sizeof(int) * ac, stream));
     ctl.alloc(1);
     HIPCHK(hipMemsetAsync(ctl.p, 0, sizeof(DevCtl), stream));
+    x4n.alloc(x4.n); fbond.alloc(ac);
+    HIPCHK(hipMemsetAsync(fbond.p, 0, sizeof(V4) * ac, stream));
+    maxima_n = cdiv(n, kIntPerBlock);
     blockmax.alloc(cdiv(ac, 256));
     HIPCHK(hipMemsetAsync(blockmax.p, 0, sizeof(unsigned long long) * cdiv(ac, 256), stream));
     eout.alloc(3 * (size_t)cdiv((long long)ac * 64, 256) + 8);
@@ -612,6 +626,37 @@ template <typename R> struct CtxT : Ctx {
     if (wait) HIPCHK(hipStreamSynchronize(stream));
   }
 
+  // Reaction steps append to these tables; their first growth (device reallocation + copy, pinned reallocation of the
+  // staging vectors: milliseconds each) is paid here, once, when a run with reactions starts -- sized for one bond
+  // per particle, beyond that they grow geometrically as before.
+  bool react_tables_reserved = false;
+  std::vector<Candidate> radix_tmp;     // scratch of the event sort (kept: a fresh 6 MB vector per step is 1.5 ms of page faults)
+  void reserve_reaction_tables() {
+    if (react_tables_reserved) return;
+    react_tables_reserved = true;
+    const size_t nt = (size_t)(nglob > 0 ? nglob : (int)top.n);
+    const size_t per = top.spawns_tuples() ? 4 : 1;      // tuples a new bond may add (itself + spawned angles / dihedrals)
+    for (auto& d : reactions) if (!d.is_virtual && d.bond_list >= 0 && d.bond_list < (int)top.lists.size()) {
+      HostList& l = top.lists[d.bond_list];
+      l.seen.reserve(l.seen.used + nt); l.ent.reserve(l.ent.size() + 2 * nt);
+    }
+    radix_tmp.reserve(nt / 2 + 1024);
+    stage_ne.reserve(nt / 2 * per + 1024); stage_nl.reserve(nt / 2 * per + 1024); stage_ep.reserve(nt / 2 * per + 1024);
+    grow(fent, fent_n, fent_n + nt * per, stream); grow(flist, fent_n, fent_n + nt * per, stream);
+    grow(epairs, epairs_n, epairs_n + nt * per, stream);
+    const size_t ub = fent_members + 2 * nt * per;
+    if (eslot.n < fent_n + nt * per) eslot.alloc(fent_n + nt * per);
+    if (bent.n < ub) { DBuf<BondedEntry> nb_; nb_.alloc(ub); if (nbent > 0) HIPCHK(hipMemcpyAsync(nb_.p, bent.p, (size_t)nbent * sizeof(BondedEntry), hipMemcpyDeviceToDevice, stream));
+                       HIPCHK(hipStreamSynchronize(stream)); std::swap(bent.p, nb_.p); std::swap(bent.n, nb_.n); bkey.alloc(ub); }
+    if (bwork.n < nt) { bwork.alloc(nt); bwork_dirty = true; }
+    if (bj.n < ub) { bj.alloc(ub); bwork_dirty = true; }
+    if (excl_list.n < 3 * (epairs_n + nt * per) + 1024) {
+      DBuf<int> nl_; nl_.alloc(3 * (epairs_n + nt * per) + 1024);
+      if (epairs_n) HIPCHK(hipMemcpyAsync(nl_.p, excl_list.p, std::min(excl_list.n, 2 * epairs_n) * sizeof(int), hipMemcpyDeviceToDevice, stream));
+      HIPCHK(hipStreamSynchronize(stream)); std::swap(excl_list.p, nl_.p); std::swap(excl_list.n, nl_.n);
+    }
+  }
+
   void upload_excl(bool full = true, bool wait = true) {
     if (full) epairs_n = 0;
     const size_t have = top.excl_log.size();
@@ -666,8 +711,8 @@ template <typename R> struct CtxT : Ctx {
     if (use_tiles) {
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c, (const int*)cell_sub.p);
       hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
-      hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
-                         excl_start.p, excl_list.p, has_excl, act, all_active ? 1 : 0, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
+      hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), list_lds_need(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
+                         excl_start.p, excl_list.p, has_excl, act, ntypes, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
     } else if (box.nc[0] > 0)
       hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
                          excl_start.p, excl_list.p, has_excl, nlist.p, nn.p, S, c);
@@ -689,7 +734,7 @@ template <typename R> struct CtxT : Ctx {
 
   void decide_and_rebuild() {
     if (use_fused) { tbeg(1); launch_rebuild_fused(); tend(); return; }
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, kIntPerBlock), 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, maxima_n, 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
     launch_rebuild_chain();
   }
 
@@ -941,6 +986,39 @@ template <typename R> struct CtxT : Ctx {
     pair_guard = 0;
   }
 
+  // Force evaluation of step `istep` with the integrator halves in the force kernel's epilogue (k_pair_tiles INTEG):
+  // bonded forces first, into their own buffer; positions of the next step go to the second buffer, swapped here.
+  bool can_fuse_pair() const {
+    return opt_fuse_pair && opt_fuse && use_tiles && use_fused && !dd_on && !opt_criterion && !resc_kind && !dbg_on && !opt_ablate &&
+           pair_bs == 512 && pick_tpp() == 1 && ntiles <= (int)blockmax.n && G == 0;
+  }
+  void compute_forces_integrate(int64_t istep) {
+    const bool timed = timed_step;
+    const bool bonded = nbent > 0;
+    if (bonded) {
+      if (bwork_dirty) {
+        HIPCHK(hipMemsetAsync(&ctl.p->bwork_count, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
+        bwork_dirty = false;
+      }
+      if (timed) tbeg(3);
+      hipLaunchKernelGGL((k_bonded_work<R, true>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, fbond.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, 0, btab_view());
+      if (timed) tend();
+    }
+    IntegArgs<R> ia{};
+    ia.xn = x4n.p; ia.v4 = v4.p; ia.tag = tag.p; ia.fb = bonded ? fbond.p : (V4*)nullptr; ia.blockmax = blockmax.p;
+    ia.dt = (R)dt; ia.cap = cap_force > 0 ? (R)cap_force : (R)0; ia.lang = lang ? 1 : 0; ia.lp = lang_params(istep, 1);
+    const TileSub ts{0, ntiles, 0};
+    if (timed) tbeg(0);
+#define LPI(M) hipLaunchKernelGGL((k_pair_tiles<R, 1, false, 512, M, false, true>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, f4.p, tdesc.p, \
+                                  nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, 0.5 * skin, ctl.p, 0, 0, (long long*)nullptr, ts, ia)
+    if (uniform_lj) LPI(2); else if (lj_only) LPI(1); else LPI(0);
+#undef LPI
+    if (timed) tend();
+    std::swap(x4.p, x4n.p);
+    maxima_n = ntiles;
+  }
+
   LangevinP<R> lang_params(int64_t istep, int phase) const {
     LangevinP<R> lp{};
     lp.on = lang ? 1 : 0; lp.kT = kT; lp.gamma = gamma; lp.dt = dt; lp.seed = lang_seed; lp.step = (uint64_t)istep; lp.phase = (uint32_t)phase;
@@ -949,6 +1027,7 @@ template <typename R> struct CtxT : Ctx {
 
   template <int MODE> void launch_integrate(bool with_lang, bool storef, int64_t istep, int phase) {
     const int nb = cdiv(n, kIntPerBlock);
+    if (MODE & 2) maxima_n = nb;
     LangevinP<R> lp = lang_params(istep, phase);
     // CapForce acts on the freshly evaluated conservative force: every launch that applies the thermostat
     // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
@@ -1070,9 +1149,8 @@ template <typename R> struct CtxT : Ctx {
         HIPCHK(hipMemcpyAsync(pin_ev, evout.p, bytes, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
       }
-      // pinned staging of the tables a bond-forming step rebuilds; sized so that growing them (a
-      // pinned reallocation costs milliseconds) is rare: one entry per particle to start with
     }
+    if (react_on && !reactions.empty()) reserve_reaction_tables();
     if (resort) rebuild_now();
     compute_forces();
     if (lang) launch_integrate<0>(true, true, step, 0);  // thermalize: f += friction + noise, stored
@@ -1080,13 +1158,16 @@ template <typename R> struct CtxT : Ctx {
     for (int64_t s = 0; s < nsteps; ++s) {
       if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
       timed_step = opt_time_pair && (pair_launch_no++ % opt_time_pair) == 0;
-      if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
-      else { decide_and_rebuild(); compute_forces(); }
-      resort = false;   // a rebuild requested by the last reaction step (force_rebuild on the device) has happened by now
-
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
       const bool last = (s == nsteps - 1);
-      if (last || react_due || !opt_fuse || resc_kind) {
+      const bool split = last || react_due || !opt_fuse || resc_kind;   // this step ends with a half-kick of its own
+      const bool fuse_pair = !split && can_fuse_pair();
+      if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
+      else { decide_and_rebuild(); if (fuse_pair) compute_forces_integrate(step); else compute_forces(); }
+      resort = false;   // a rebuild requested by the last reaction step (force_rebuild on the device) has happened by now
+
+      if (fuse_pair) ++step;
+      else if (split) {
         launch_integrate<1>(lang, lang, step, 1);
         ++step;
         if (resc_kind == 1 || resc_kind == 3 || (resc_kind == 2 && step % (int64_t)resc_param == 0)) rescale_velocities();
@@ -1288,8 +1369,8 @@ template <typename R> struct CtxT : Ctx {
       // A particle takes part in at most one event per reaction step, so min(a,b) alone is a unique
       // key: LSD radix sort (3 x 11 bits) instead of a comparison sort of 10^5 events.
       const size_t m = (size_t)(mid - hev.begin());
-      std::vector<Candidate> tmp(m);
-      Candidate* src = hev.data(); Candidate* dst = tmp.data();
+      if (radix_tmp.size() < m) radix_tmp.resize(m);
+      Candidate* src = hev.data(); Candidate* dst = radix_tmp.data();
       for (int pass = 0; pass < 3; ++pass) {
         size_t cnt[2049] = {0};
         const int sh = 11 * pass;
@@ -1304,6 +1385,7 @@ template <typename R> struct CtxT : Ctx {
       if (!unique) std::sort(hev.begin(), mid, [&](const Candidate& p, const Candidate& q) { return ekey(p) < ekey(q); });
     }
     std::vector<std::pair<int32_t, int32_t>> newbonds;
+    newbonds.reserve(hev.size());
     bool types_changed = false;
     // event log + host mirrors of the new types (only what the host itself needs later: types for
     // bonded-slot resolution and the topology manager; chemical states live on the device).  Events
@@ -1566,7 +1648,51 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void set_pair_bs(int v) override { pair_bs = v; }
-  void debug_enable(int on) override { dbg_on = on != 0; if (dbg_on) { dbgbuf.alloc(6 * (size_t)std::max(ntiles, 1)); } }
+  void debug_enable(int on) override {
+    dbg_on = on != 0;
+    if (dbg_on) { dbgbuf.alloc(6 * (size_t)std::max(ntiles, 1)); wgst.alloc(8 * (size_t)std::max(fused_grid, 1)); HIPCHK(hipMemsetAsync(wgst.p, 0, 8 * sizeof(long long) * (size_t)std::max(fused_grid, 1), stream)); }
+  }
+  // diagnostic / tests: the 16-bit force list of one particle as partner tags, in list order (padding dropped)
+  int64_t debug_force_list(int tg, int32_t* out, int64_t cap) override {
+    if (!use_tiles || !device_ready) return -1;
+    HIPCHK(hipStreamSynchronize(stream));
+    int p = -1; HIPCHK(hipMemcpy(&p, rtag.p + tg, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<TileLDS<R>> hd(ntiles);
+    HIPCHK(hipMemcpy(hd.data(), tdesc.p, sizeof(TileLDS<R>) * (size_t)ntiles, hipMemcpyDeviceToHost));
+    std::vector<int> htag; tag.download(htag, acap(), stream);
+    for (int t = 0; t < ntiles; ++t) {
+      const TileLDS<R>& T = hd[t];
+      for (int sg = 0; sg < NHSEG; ++sg) {
+        const int cnt = T.hoff[sg + 1] - T.hoff[sg];
+        if (p < T.hstart[sg] || p >= T.hstart[sg] + cnt) continue;
+        const int q = T.hoff[sg] + (p - T.hstart[sg]), nhome = T.geom[4], hbase = T.geom[5];
+        int n16 = 0; HIPCHK(hipMemcpy(&n16, nnh.p + hbase + q, sizeof(int), hipMemcpyDeviceToHost));
+        int64_t m = 0;
+        for (int c = 0; c * 8 < n16; ++c) {
+          unsigned short ch[8];
+          HIPCHK(hipMemcpy(ch, nl16.p + (size_t)hbase * S + ((size_t)c * nhome + q) * 8, 16, hipMemcpyDeviceToHost));
+          for (int k = 0; k < 8 && c * 8 + k < n16; ++k) {
+            const int sl = ch[k];
+            int r = 0; while (r + 1 < NROW && sl >= T.rowoff[r + 1]) ++r;
+            const int e = sl - T.rowoff[r];
+            int kc = 0; for (int qq = 1; qq < SX; ++qq) kc += e >= T.celloff[r][qq] ? 1 : 0;
+            const int j = T.cellg[r][kc] + (e - T.celloff[r][kc]);
+            if (m < cap) out[m] = htag[j];
+            ++m;
+          }
+        }
+        return m;
+      }
+    }
+    return -1;
+  }
+  int64_t debug_dump_rebuild(long long* out, int64_t cap) override {
+    if (!dbg_on || !use_fused) return 0;
+    std::vector<long long> h; wgst.download(h, 8 * (size_t)fused_grid, stream);
+    const int64_t m = std::min<int64_t>(cap, (int64_t)h.size());
+    std::copy(h.begin(), h.begin() + m, out);
+    return m;
+  }
   int64_t debug_dump(long long* out, int64_t cap) override {
     if (!dbg_on) return 0;
     std::vector<long long> h; dbgbuf.download(h, 6 * (size_t)ntiles, stream);
@@ -1981,6 +2107,8 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   if (k == "tpp") { const int v = (int)value; REQUIRE(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64, CHEM_EINVAL, "tpp must be a power of two <= 64"); CTX.opt_tpp = v; }
   else if (k == "time_pair_kernel") CTX.opt_time_pair = value > 0 ? (int)value : 0;
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
+  else if (k == "fuse_pair_integrate") CTX.opt_fuse_pair = value != 0;
+  else if (k == "ablate_list") CTX.opt_ablate_list = (int)value;
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else if (k == "fused_rebuild") { CTX.opt_fused = value != 0; CTX.geom_dirty = true; }
   else if (k == "overlap_halo") CTX.opt_overlap = value < 0 ? -1 : (value != 0 ? 1 : 0);
@@ -2007,6 +2135,10 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
 
 // diagnostic: per-tile phase stamps of the last pair-force launch (6 int64 per tile); not part of the public header
 int64_t chem_debug_dump(chem_ctx* ctx, long long* out, int64_t cap) { return ctx->c->debug_dump(out, cap); }
+// diagnostic: 8 int64 per workgroup of the last rebuilding k_rebuild_fused launch (phase stamps, tiles done)
+int64_t chem_debug_dump_rebuild(chem_ctx* ctx, long long* out, int64_t cap) { return ctx->c->debug_dump_rebuild(out, cap); }
+// diagnostic / tests: partner tags of the force list of particle `tag`, in list order; -1 without tiles
+int64_t chem_debug_force_list(chem_ctx* ctx, int32_t tag, int32_t* out, int64_t cap) { try { return ctx->c->debug_force_list(tag, out, cap); } catch (...) { return -2; } }
 
 int chem_comm_unique_id(char uid[128]) {
   RcclApi& a = rccl_api();

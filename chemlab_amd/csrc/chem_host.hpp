@@ -56,6 +56,14 @@ struct TupleSet {
     slot.assign(old.empty() ? 1024 : old.size() * 2, TupleKey{~0ull, ~0ull}); used = 0;
     for (auto& k : old) if (!empty_key(k)) insert(k);
   }
+  void reserve(size_t want) {   // room for `want` keys without a re-hash
+    size_t cap = slot.empty() ? 1024 : slot.size();
+    while ((want + 1) * 10 >= cap * 7) cap *= 2;
+    if (cap == slot.size()) return;
+    std::vector<TupleKey> old; old.swap(slot);
+    slot.assign(cap, TupleKey{~0ull, ~0ull}); used = 0;
+    for (auto& k : old) if (!empty_key(k)) insert(k);
+  }
   void prefetch(const TupleKey& k) const { if (!slot.empty()) __builtin_prefetch(&slot[TupleKeyHash()(k) & (slot.size() - 1)]); }
   bool insert(const TupleKey& k) {
     if ((used + 1) * 10 >= slot.size() * 7) grow();

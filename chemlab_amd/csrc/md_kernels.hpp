@@ -21,6 +21,29 @@ template <> struct Vec4T<float> { using type = float4; };
 template <> struct Vec4T<double> { using type = double4; };
 template <typename R> using Vec4 = typename Vec4T<R>::type;
 
+// streaming (non-temporal) 16/32-byte stores for write-once outputs: the lines do not stay dirty in the L2,
+// so they are not written back at the kernel boundary
+#ifndef CHEM_EXP_NT
+#define CHEM_EXP_NT 0
+#endif
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+typedef double f64x2_nt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream(float4* p, const float4& v) {
+#if CHEM_EXP_NT
+  const f32x4_nt t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<f32x4_nt*>(p));
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(double4* p, const double4& v) {
+#if CHEM_EXP_NT
+  const f64x2_nt a = {v.x, v.y}, b = {v.z, v.w};
+  __builtin_nontemporal_store(a, reinterpret_cast<f64x2_nt*>(p)); __builtin_nontemporal_store(b, reinterpret_cast<f64x2_nt*>(p) + 1);
+#else
+  *p = v;
+#endif
+}
+
 template <typename R> __device__ __forceinline__ Vec4<R> mk4(R a, R b, R c, R d);
 template <> __device__ __forceinline__ float4 mk4<float>(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
 template <> __device__ __forceinline__ double4 mk4<double>(double a, double b, double c, double d) { return make_double4(a, b, c, d); }
@@ -163,12 +186,12 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
       Vec4<R> x = xx[u];
       R dx = dt * v.x, dy = dt * v.y, dz = dt * v.z;
       x.x += dx; x.y += dy; x.z += dz;
-      x4[i] = x;
+      st_stream(&x4[i], x);
       if (x0) { const Vec4<R> o = x0[i]; dx = x.x - o.x; dy = x.y - o.y; dz = x.z - o.z; }
       const R dd = dx * dx + dy * dy + dz * dz;
       d2 = dd > d2 ? dd : d2;
     }
-    v4[i] = v;
+    st_stream(&v4[i], v);
   }
   if (MODE & 2) {
     // max |dx|^2 of the block -> blockmax[blockIdx.x]; folded by k_rebuild_decide (no contended atomics)
@@ -968,25 +991,38 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
     for (int k = 0; k < SX; ++k) { o += T.celloff[t][k + 1]; T.celloff[t][k + 1] = o; }
   }
   __syncthreads();
-  if (t == 0) {
-    int o = 0;
-    for (int r = 0; r < NROW; ++r) { T.rowoff[r] = o; o += T.celloff[r][SX]; }
-    T.rowoff[NROW] = o;
-    if (o > CAP) atomicMax(&ctl->stage_overflow, o);
-    const int total = o < CAP ? o : CAP;
-    int ho = 0;
-    for (int hzi = 0; hzi < HZ; ++hzi) for (int hyi = 0; hyi < HY; ++hyi) {
-      const int sgi = hzi * HY + hyi;
-      int st = 0, cn = 0;
-      if (hyi < hy && hzi < hz) {
-        const int c0 = ((cz0 + hzi) * ny + (cy0 + hyi)) * nx + cx0;
-        st = cell_start[c0]; cn = cell_start[c0 + hx] - st;
-      }
-      T.hstart[sgi] = st; T.hoff[sgi] = ho; ho += cn;
+  // Third step, three waves side by side, everything from the LDS tables of the first two steps (the home cells are
+  // among the 125 stencil cells): a single thread walking 25 rows and 9 home runs with dependent loads cost ~10 us
+  // per tile in the rebuild, where these tables are computed (the force kernel reads them back from HBM).
+  const int wv = t >> 6, ln = t & 63;
+  if (wv == 0) {          // first slot of every stencil row
+    const int len = ln < NROW ? T.celloff[ln][SX] : 0;
+    int incl = len;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const int u = __shfl_up(incl, o); if (ln >= o) incl += u; }
+    if (ln < NROW) T.rowoff[ln] = incl - len;
+    if (ln == NROW - 1) {
+      T.rowoff[NROW] = incl;
+      if (incl > CAP) atomicMax(&ctl->stage_overflow, incl);
+      T.geom[3] = incl < CAP ? incl : CAP;
     }
-    T.hoff[NHSEG] = ho;
-    T.geom[0] = hx; T.geom[1] = hy; T.geom[2] = hz; T.geom[3] = total; T.geom[4] = ho;
+  } else if (wv == 1) {   // (blocks of >= 128 threads) home x-runs (contiguous in memory): global start, prefix of counts
+    const int hyi = ln % HY, hzi = ln / HY;
+    int st = 0, cn = 0;
+    if (ln < NHSEG && hyi < hy && hzi < hz) {
+      const int hr = (hzi + 1) * SY + (hyi + 1);
+      st = T.cellg[hr][1]; cn = T.celloff[hr][hx + 1] - T.celloff[hr][1];
+    }
+    int incl = cn;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const int u = __shfl_up(incl, o); if (ln >= o) incl += u; }
+    if (ln < NHSEG) { T.hstart[ln] = st; T.hoff[ln] = incl - cn; }
+    if (ln == NHSEG - 1) { T.hoff[NHSEG] = incl; T.geom[4] = incl; }
+  }
+  if (t == (int)blockDim.x - 1) {
+    T.geom[0] = hx; T.geom[1] = hy; T.geom[2] = hz;
     T.geom[6] = cx0 | (cy0 << 10) | (cz0 << 20);   // first home cell (list build: slot of an excluded partner)
+    T.geom[7] = 0;                                 // set by list_stage_f32: a stencil cell without x-slice information
     // geometry of the staged image (list build, x-window of a row).  In z-ghost mode layer l of the slab is the
     // global layer z0g + l - 1; the staged z of the ghost layers carries shz_lo / shz_hi, which continues the
     // same affine map across the periodic boundary.
@@ -1107,20 +1143,67 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
   }
 }
 
-// List build, fp32: the stencil staged as PAIRS of slots in SoA order -- 32 bytes per pair:
-// (x0 x1 y0 y1 | z0 z1 w0 w1) -- so that the distance test of two candidates is three v_pk_add_f32,
-// one v_pk_mul_f32 and two v_pk_fma_f32 on whole ds_read_b128 results (packed fp32 runs at twice the
-// scalar rate on CDNA3/4; with the per-slot float4 layout the compiler needs v_mov shuffles to pair
-// the operands up and gains nothing).  .w = (global index << 5 | type) as in tile_fill's wmode 1.
+// List build, fp32: LDS layout of one staged tile (inside the same dynamic LDS block the force kernel uses for its
+// float4 image -- 12 + ntypes/8 bytes per slot instead of 16):
+//   img   groups of FOUR slots in SoA order, 64 bytes per group: u0..u3 | v0..v3 | w0..w3 | q0..q3 with (u,v,w) the
+//         position relative to the lower corner of the tile's stencil (|u| <= 5 cell edges) and q = u^2+v^2+w^2.  The
+//         test of a candidate is  rl^2 + delta - |ri|^2 - q + 2 ri.(u,v,w) >= 0 : one packed add and three packed FMAs per
+//         TWO candidates instead of 3 sub + 1 mul + 2 fma + 1 sub each -- the loop is bound by VALU issue.  The
+//         expanded form loses ~6e-5 absolute on r^2 (coordinates <= 14), which `delta` covers: the 16-bit force list
+//         is a SUPERSET by a shell of 5e-5 (the force kernel applies the exact cutoff); the int32 rows re-test their
+//         hits with the difference form and stay exact;
+//   tmask one bit per slot and home type ti: "the pair (ti, type of the slot) carries a potential" (MSB first: slot s
+//         is bit 31 - (s & 31) of word s >> 5).  The type filter of a 32-candidate segment is one funnel shift of two
+//         words instead of two instructions per candidate;
+//   bnd   slot offset (inside its row) of every x-slice boundary of every stencil row: 5 cells x 4 slices + 1 values,
+//         so that the x-window of a row is two 16-bit reads (was: two table reads and bit-field arithmetic per end).
+// geom[7] of the tile tables is set when a stencil cell has no slice information (crowded cell): whole-cell windows then.
+struct ActMask { unsigned int row[kMaxTypes]; };   // bit tj of row[ti]: pair (ti,tj) has a potential
+#define CHEM_LDS __attribute__((address_space(3)))
+constexpr int NBND = SX * NSUB + 1;
+#ifndef CHEM_LIST_DELTA
+#define CHEM_LIST_DELTA 2.5e-4f
+#endif
+constexpr float kListDelta = CHEM_LIST_DELTA;   // see the layout note below: what the expanded distance form may lose on r^2
+struct ListLDS { int img_bytes, nwords, tmask_off, bnd_off; };
+__device__ __forceinline__ ListLDS list_lds_layout(int CAP, int ntypes) {
+  ListLDS L;
+  L.img_bytes = (((CAP + 3) >> 2) + 3) * 64;          // (+ three groups: the pipelined reads run up to two groups past the last slot)
+  L.nwords = ((CAP + 31) >> 5) + 2;
+  L.tmask_off = L.img_bytes;
+  L.bnd_off = L.tmask_off + ntypes * L.nwords * 4;
+  return L;
+}
+__host__ __device__ constexpr size_t list_lds_bytes(int CAP, int ntypes) {
+  return (size_t)(((CAP + 3) >> 2) + 3) * 64 + (size_t)ntypes * (((CAP + 31) >> 5) + 2) * 4 + (size_t)NROW * NBND * 2 + 16;
+}
+
+// zeroes the type masks (call before the workgroup barriers of tile_tables) ...
 template <int BS>
-__device__ __forceinline__ int pair_off(int s, int c) { return (s >> 1) * 8 + c * 2 + (s & 1); }
+__device__ __forceinline__ void list_stage_clear(unsigned char* lds, const ListLDS& L, int ntypes) {
+  CHEM_LDS unsigned int* tm = (CHEM_LDS unsigned int*)((CHEM_LDS unsigned char*)lds + L.tmask_off);
+  for (int k = threadIdx.x; k < ntypes * L.nwords; k += BS) tm[k] = 0u;
+}
+// ... and stages coordinates, type masks and slice boundaries of the tile described by T (caller synchronises afterwards)
 template <int BS>
-__device__ __forceinline__ void tile_fill_pairs(const TileLDS<float>& T, float* const sf, const int CAP, const float4* __restrict__ x4) {
+__device__ __forceinline__ void list_stage_f32(TileLDS<float>& T, unsigned char* lds, const ListLDS& L, const int CAP,
+                                               const float4* __restrict__ x4, const ActMask& act, int ntypes) {
   constexpr int NW = BS / 64;
+  // explicit LDS address space: through a generic pointer these become flat_* accesses (and flat atomics)
+  CHEM_LDS unsigned char* const l3 = (CHEM_LDS unsigned char*)lds;
+  CHEM_LDS float* img = (CHEM_LDS float*)l3;
+  CHEM_LDS unsigned int* tm = (CHEM_LDS unsigned int*)(l3 + L.tmask_off);
+  CHEM_LDS unsigned short* bnd = (CHEM_LDS unsigned short*)(l3 + L.bnd_off);
   const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-  if (threadIdx.x < 2) {   // far-away dummy in the two slots behind the image (reads run past the last run)
-    const int s = T.geom[3] + (int)threadIdx.x;
-    sf[pair_off<BS>(s, 0)] = 1e18f; sf[pair_off<BS>(s, 1)] = 1e18f; sf[pair_off<BS>(s, 2)] = 1e18f; sf[pair_off<BS>(s, 3)] = 0.f;
+  for (int t = threadIdx.x; t < NROW * NBND; t += BS) {
+    const int r = t / NBND, f = t - r * NBND, k = f >> 2, j = f & 3;
+    int v = T.celloff[r][k < SX ? k : SX];
+    if (k < SX && j) {
+      const int pk = T.cellsub[r][k];
+      if (pk < 0) { if (T.celloff[r][k + 1] > T.celloff[r][k]) T.geom[7] = 1; }
+      else v += (pk >> (8 * (j - 1))) & 0xff;
+    }
+    bnd[t] = (unsigned short)v;
   }
   for (int r = w; r < NROW; r += NW) {
     const int len = T.celloff[r][SX], o0 = T.rowoff[r];
@@ -1132,10 +1215,13 @@ __device__ __forceinline__ void tile_fill_pairs(const TileLDS<float>& T, float* 
       const int dst = o0 + e;
       if (dst < CAP) {
         const float4 p = x4[g];
-        sf[pair_off<BS>(dst, 0)] = p.x + T.cellshx[r][k];
-        sf[pair_off<BS>(dst, 1)] = p.y + T.rowshy[r];
-        sf[pair_off<BS>(dst, 2)] = p.z + T.rowshz[r];
-        sf[pair_off<BS>(dst, 3)] = __int_as_float((g << 5) | (int)p.w);
+        CHEM_LDS float* grp = img + (dst >> 2) * 16 + (dst & 3);
+        const float u = (p.x + T.cellshx[r][k]) - T.org[0], v = (p.y + T.rowshy[r]) - T.org[1], w_ = (p.z + T.rowshz[r]) - T.org[2];
+        grp[0] = u; grp[4] = v; grp[8] = w_; grp[12] = fmaf(u, u, fmaf(v, v, w_ * w_));   // (explicit: the same rounding in every kernel this is inlined into)
+        const int tj = (int)p.w & 15;
+        const unsigned int bit = 0x80000000u >> (dst & 31);
+        for (int ti = 0; ti < ntypes; ++ti)
+          if ((act.row[ti] >> tj) & 1u) __hip_atomic_fetch_or(&tm[ti * L.nwords + (dst >> 5)], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
@@ -1171,7 +1257,6 @@ __device__ __forceinline__ int ntiles_of(const int nc[3]) {
 // One lane per home particle walks the nine x-runs of its 27-cell stencil in the staged LDS image:
 // no cross-lane traffic, every lane does useful work (the wave-per-particle ballot version spent
 // ~7x more instructions per accepted pair).
-struct ActMask { unsigned int row[kMaxTypes]; };   // bit tj of row[ti]: pair (ti,tj) has a potential
 
 // list build of ONE staged tile (T and sx filled, block synchronised): see k_nlist_tiles
 template <typename R, int BS>
@@ -1193,51 +1278,12 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
       int lx = 0;
       for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
       const int sself = T.rowoff[hr] + eh;
-      Vec4<R> xi;
-      if constexpr (sizeof(R) == 4) {   // paired SoA image (tile_fill_pairs)
-        const float* sf = reinterpret_cast<const float*>(sx);
-        xi = mk4<R>(sf[pair_off<BS>(sself, 0)], sf[pair_off<BS>(sself, 1)], sf[pair_off<BS>(sself, 2)], sf[pair_off<BS>(sself, 3)]);
-      } else xi = sx[sself];
+      const Vec4<R> xi = sx[sself];
       const unsigned int arow = act.row[real_as_idx(xi.w) & 15];
       int e0 = 0, e1 = 0;
       if (has_excl) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
       int cnt = 0, cnt16 = 0;
       int* row32 = nlist ? nlist + (size_t)p * S : nullptr;
-      // Exclusions without leaving the plain path (single domain): the few excluded partners of a
-      // particle are located in the staged tile ONCE (tag -> index -> position -> cell -> slot, the
-      // binning arithmetic repeated on the same bits) and their bits are cleared from the hit masks,
-      // like the self pair.  Otherwise every hit of a bonded particle would need the candidate's tag
-      // from global memory.  More than 4 exclusions: generic path below.
-      int xs0 = -1, xs1 = -1, xs2 = -1, xs3 = -1;
-      bool fastx = false;
-      if (bx && e1 > e0 && e1 - e0 <= 4 && !row32) {
-        fastx = true;
-        const int org = T.geom[6];
-        const int nx = bx->nc[0], ny = bx->nc[1], nz = bx->nc[2];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          int slot = -1;
-          if (e0 + k < e1) {
-            const int g = rtag[excl_list[e0 + k]];
-            if (g >= 0) {
-              const Vec4<R> xg = x4[g];
-              int cx = (int)(xg.x * bx->cell_inv[0]), cy = (int)(xg.y * bx->cell_inv[1]), cz = (int)(xg.z * bx->cell_inv[2]);
-              cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx); cy = cy >= ny ? ny - 1 : (cy < 0 ? 0 : cy); cz = cz >= nz ? nz - 1 : (cz < 0 ? 0 : cz);
-              int kx = cx - (org & 1023) + 1, ky = cy - ((org >> 10) & 1023) + 1, kz = cz - (org >> 20) + 1;
-              kx += kx < 0 ? nx : 0; kx -= kx >= nx ? nx : 0;
-              ky += ky < 0 ? ny : 0; ky -= ky >= ny ? ny : 0;
-              kz += kz < 0 ? nz : 0; kz -= kz >= nz ? nz : 0;
-              if (kx < hx + 2 && ky < T.geom[1] + 2 && kz < T.geom[2] + 2) {
-                const int rr = kz * SY + ky, off = g - T.cellg[rr][kx];
-                if (off >= 0 && off < T.celloff[rr][kx + 1] - T.celloff[rr][kx]) slot = T.rowoff[rr] + T.celloff[rr][kx] + off;
-                else ctl->excl_slot_error = 1;
-              }
-            }
-          }
-          if (k == 0) xs0 = slot; else if (k == 1) xs1 = slot; else if (k == 2) xs2 = slot; else xs3 = slot;
-        }
-      }
-      const bool plain = (e1 == e0 || fastx) && !row32;
       uint4* regq = reinterpret_cast<uint4*>(reg16) + q;   // chunk c of this particle: regq[c * nhome]
       // accepted slots are shifted into a 128-bit register; every 8th append stores one whole
       // 16-byte chunk (instead of eight scattered 2-byte stores)
@@ -1300,68 +1346,6 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
         const int a = T.rowoff[r] + suboff(r, f_lo, true);
         int b = T.rowoff[r] + suboff(r, f_hi + 1, false);
         b = b < total ? b : total;
-        if constexpr (sizeof(R) == 4) {
-          // fp32 fast path: 32-candidate segments (16 slot pairs), one 32-bit shift-register mask per
-          // lane.  Two candidates per packed instruction: 3 v_pk_add + v_pk_mul + 2 v_pk_fma, then per
-          // candidate v_cmp + v_addc (the carry shifts the result in) and v_bfe + v_lshl_or for the
-          // type-pair filter.  Segments start on an even slot; the slot in front of an odd run start and
-          // the (up to 3) slots behind the run are tested too and masked off afterwards.
-          typedef float f32x4 __attribute__((ext_vector_type(4)));
-          typedef float f32x2 __attribute__((ext_vector_type(2)));
-          typedef __attribute__((address_space(3))) const volatile f32x4 lds_f32x4;   // volatile: keeps the 16-byte reads
-          const f32x2 xix = {xi.x, xi.x}, xiy = {xi.y, xi.y}, xiz = {xi.z, xi.z};
-          for (int s0 = a & ~1; s0 < b; s0 += 32) {
-            const int len = (b - s0) < 32 ? (b - s0) : 32;
-            const int ng = (len + 3) >> 2;
-            unsigned int m = 0, ma = 0;
-            lds_f32x4* base = (lds_f32x4*)(sx) + s0;      // pair p = slot/2 lives at float4 index 2p, 2p+1 = slots s0, s0+1
-            for (int g = 0; g < ng; ++g) {
-              f32x4 A[2], B[2];
-#pragma unroll
-              for (int u = 0; u < 2; ++u) { A[u] = base[4 * g + 2 * u]; B[u] = base[4 * g + 2 * u + 1]; }
-#pragma unroll
-              for (int u = 0; u < 2; ++u) {
-                const f32x2 dx = xix - A[u].xy, dy_ = xiy - A[u].zw, dz_ = xiz - B[u].xy;
-                const f32x2 r2 = dx * dx + dy_ * dy_ + dz_ * dz_;
-                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r2.x), "v"(rl2) : "vcc");
-                ma = (ma << 1) | __builtin_amdgcn_ubfe(arow, __float_as_uint(B[u].z), 1u);   // type pair carries a potential
-                asm("v_cmp_le_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(r2.y), "v"(rl2) : "vcc");
-                ma = (ma << 1) | __builtin_amdgcn_ubfe(arow, __float_as_uint(B[u].w), 1u);
-              }
-            }
-            m <<= 32 - 4 * ng;                                     // candidate u -> bit 31-u
-            m &= ~(len < 32 ? (0xffffffffu >> len) : 0u);
-            if (s0 < a) m &= 0x7fffffffu;                          // the slot in front of an odd run start
-            if (plain) {
-              // no exclusions (or located as slots) and no int32 row for this particle: the type filter was
-              // folded into the test loop (ma) and the self pair is cleared from the mask, so a hit needs
-              // nothing from memory and the peel loop has no LDS latency in it
-              m &= ma << (32 - 4 * ng);
-              const unsigned int ks = (unsigned int)(sself - s0);
-              if (ks < 32u) m &= ~(0x80000000u >> ks);
-              if (fastx) {
-                const unsigned int k0 = (unsigned int)(xs0 - s0), k1 = (unsigned int)(xs1 - s0), k2 = (unsigned int)(xs2 - s0), k3 = (unsigned int)(xs3 - s0);
-                if (k0 < 32u) m &= ~(0x80000000u >> k0);
-                if (k1 < 32u) m &= ~(0x80000000u >> k1);
-                if (k2 < 32u) m &= ~(0x80000000u >> k2);
-                if (k3 < 32u) m &= ~(0x80000000u >> k3);
-              }
-              while (m) {
-                const int k = __clz((int)m);
-                m &= ~(0x80000000u >> k);
-                push((unsigned int)(s0 + k));
-              }
-            } else {
-              const float* sf = reinterpret_cast<const float*>(sx);
-              while (m) {
-                const int k = __clz((int)m);
-                m &= ~(0x80000000u >> k);
-                const int sl = s0 + k;
-                hit(sl, __float_as_int(sf[pair_off<BS>(sl, 3)]));
-              }
-            }
-          }
-        } else {
         for (int s0 = a; s0 < b; s0 += 64) {
           const int len = (b - s0) < 64 ? (b - s0) : 64;
           unsigned int mlo = 0, mhi = 0;
@@ -1386,7 +1370,6 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
             hit(s, real_as_idx(sx[s].w));
           }
         }
-        }
       }
       // pad the last chunk with the far-away dummy slot (chunks are read whole)
       const int real16 = cnt16;
@@ -1402,11 +1385,225 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
     }
 }
 
+// fp32 list build of ONE tile staged by list_stage_f32 (workgroup synchronised).  Same products as dev_nlist_tile.
+// Per home particle (one lane each) and stencil row: x-window [a, b) from the slice-boundary table, then segments of
+// up to 32 candidates = 8 groups of four slots; the next group's three ds_read_b128 are issued before the current
+// one is evaluated, and the window of the NEXT row is looked up before this row's candidates are walked, so that the
+// LDS latencies hide behind arithmetic instead of adding up (the lanes are latency-bound: 24 waves per CU is all the
+// 45 KB image allows).  A test leaves its result in the sign bit of rl^2 - r^2, which one v_alignbit per candidate
+// shifts into the segment's miss mask.  Hits surviving the type mask (and, located as slots, the self pair and up to
+// four excluded partners) are peeled off and appended to the lane's 16-byte chunk register.
+template <int BS>
+__device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsigned char* lds, const ListLDS& L, const int* tag, const float rl2,
+                                                   const int* excl_start, const int* excl_list, const int has_excl,
+                                                   unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl,
+                                                   const Box<float>* bx, const int* rtag, const float4* x4, const int ablate = 0) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) const volatile f32x4 lds_f32x4;   // volatile: keeps the 16-byte reads and their order
+  CHEM_LDS unsigned char* const l3 = (CHEM_LDS unsigned char*)lds;   // (explicit LDS address space: ds_read, not flat_load)
+  const CHEM_LDS float* img = (const CHEM_LDS float*)l3;
+  const CHEM_LDS unsigned int* tmask = (const CHEM_LDS unsigned int*)(l3 + L.tmask_off);
+  const CHEM_LDS unsigned short* bnd = (const CHEM_LDS unsigned short*)(l3 + L.bnd_off);
+  const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4], hbase = T.geom[5];
+  const bool nowin = T.geom[7] != 0;
+  unsigned short* reg16 = nl16 + (size_t)hbase * S16;
+  for (int q = threadIdx.x; q < nhome; q += BS) {
+    int sgi = 0;
+#pragma unroll
+    for (int k = 1; k < NHSEG; ++k) sgi += (q >= T.hoff[k]) ? 1 : 0;
+    const int inrun = q - T.hoff[sgi];
+    const int p = T.hstart[sgi] + inrun;
+    const int ly = sgi % HY, lz = sgi / HY;
+    const int hr = (lz + 1) * SY + (ly + 1);
+    const int eh = inrun + T.celloff[hr][1];
+    int lx = 0;
+    for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
+    const int sself = T.rowoff[hr] + eh;
+    const CHEM_LDS float* self = img + (sself >> 2) * 16 + (sself & 3);
+    const float xix = self[0], xiy = self[4], xiz = self[8];             // relative to the stencil's lower corner
+    const float cq = rl2 + kListDelta - self[12];
+    const f32x2 ax = {2.f * xix, 2.f * xix}, ay = {2.f * xiy, 2.f * xiy}, az = {2.f * xiz, 2.f * xiz}, cc = {cq, cq};
+    const int ti = (int)x4[p].w & 15;                 // home cells carry no periodic shift: x4[p] is the staged particle
+    const CHEM_LDS unsigned int* tmrow = tmask + ti * L.nwords;
+    int e0 = 0, e1 = 0;
+    if (has_excl) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
+    int cnt = 0, cnt16 = 0;
+    int* row32 = nlist ? nlist + (size_t)p * S : nullptr;
+    // Exclusions without leaving the plain path (single domain): the few excluded partners of a particle are located
+    // in the staged tile ONCE (tag -> index -> position -> cell -> slot, the binning arithmetic repeated on the same
+    // bits) and their bits are cleared from the hit masks, like the self pair.  More than 4 exclusions: generic path.
+    int xs0 = -1, xs1 = -1, xs2 = -1, xs3 = -1;
+    bool fastx = false;
+    if (bx && e1 > e0 && e1 - e0 <= 4 && !row32) {
+      fastx = true;
+      const int org = T.geom[6];
+      const int nx = bx->nc[0], ny = bx->nc[1], nz = bx->nc[2];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        int slot = -1;
+        if (e0 + k < e1) {
+          const int g = rtag[excl_list[e0 + k]];
+          if (g >= 0) {
+            const float4 xg = x4[g];
+            int cx = (int)(xg.x * bx->cell_inv[0]), cy = (int)(xg.y * bx->cell_inv[1]), cz = (int)(xg.z * bx->cell_inv[2]);
+            cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx); cy = cy >= ny ? ny - 1 : (cy < 0 ? 0 : cy); cz = cz >= nz ? nz - 1 : (cz < 0 ? 0 : cz);
+            int kx = cx - (org & 1023) + 1, ky = cy - ((org >> 10) & 1023) + 1, kz = cz - (org >> 20) + 1;
+            kx += kx < 0 ? nx : 0; kx -= kx >= nx ? nx : 0;
+            ky += ky < 0 ? ny : 0; ky -= ky >= ny ? ny : 0;
+            kz += kz < 0 ? nz : 0; kz -= kz >= nz ? nz : 0;
+            if (kx < hx + 2 && ky < T.geom[1] + 2 && kz < T.geom[2] + 2) {
+              const int rr = kz * SY + ky, off = g - T.cellg[rr][kx];
+              if (off >= 0 && off < T.celloff[rr][kx + 1] - T.celloff[rr][kx]) slot = T.rowoff[rr] + T.celloff[rr][kx] + off;
+              else ctl->excl_slot_error = 1;
+            }
+          }
+        }
+        if (k == 0) xs0 = slot; else if (k == 1) xs1 = slot; else if (k == 2) xs2 = slot; else xs3 = slot;
+      }
+    }
+    const bool plain = (e1 == e0 || fastx) && !row32;
+    uint4* regq = reinterpret_cast<uint4*>(reg16) + q;   // chunk c of this particle: regq[c * nhome]
+    // accepted slots are shifted into a 128-bit register; every 8th append stores one whole 16-byte chunk
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    auto push = [&](unsigned int sl) {
+      acc.x = __builtin_amdgcn_alignbit(acc.y, acc.x, 16);
+      acc.y = __builtin_amdgcn_alignbit(acc.z, acc.y, 16);
+      acc.z = __builtin_amdgcn_alignbit(acc.w, acc.z, 16);
+      acc.w = (acc.w >> 16) | (sl << 16);
+      if ((cnt16 & 7) == 7 && cnt16 < S16 && ablate != 2) regq[(size_t)(cnt16 >> 3) * nhome] = acc;
+      ++cnt16;
+    };
+    // x-window of stencil row dzy: a candidate in row (dy, dz) is at least (ddy, ddz) away in y and z (distance of the
+    // home particle from that row's slab), so only x within sqrt(rl^2 - ddy^2 - ddz^2) can be a neighbour -- 46 % of the
+    // 3-cell run on average.  `weps` absorbs every rounding difference between the binning arithmetic and this one (the
+    // slices only prune, the distance test decides membership).
+    const float weps = T.clen[0] * 2e-4f;
+    const float ylo = (float)(ly + 1) * T.clen[1], zlo = (float)(lz + 1) * T.clen[2];
+    const float dylo = fmaxf(xiy - ylo - weps, 0.f), dyhi = fmaxf(ylo + T.clen[1] - xiy - weps, 0.f);
+    const float dzlo = fmaxf(xiz - zlo - weps, 0.f), dzhi = fmaxf(zlo + T.clen[2] - xiz - weps, 0.f);
+    const float sxi = xix * T.subinv;
+    const int fmin = lx * NSUB, fmax = (lx + 3) * NSUB - 1;
+    auto window = [&](int dzy, int& a, int& b) {
+      const int dz = dzy / 3, dy = dzy - 3 * dz;
+      const int r = (lz + dz) * SY + (ly + dy);
+      const float ddy = dy == 0 ? dylo : (dy == 2 ? dyhi : 0.f), ddz = dz == 0 ? dzlo : (dz == 2 ? dzhi : 0.f);
+      const float w2 = rl2 - ddy * ddy - ddz * ddz;
+      int f_lo = fmin, f_hi = fmax;
+      if (!nowin) {
+        const float ws = (__builtin_amdgcn_sqrtf(fmaxf(w2, 0.f)) + weps) * T.subinv;
+        const int g_lo = (int)(sxi - ws), g_hi = (int)(sxi + ws);     // truncation == floor where it matters (clamped at >= fmin)
+        f_lo = g_lo > fmin ? g_lo : fmin; f_lo = f_lo < fmax ? f_lo : fmax; f_hi = g_hi < fmax ? g_hi : fmax; f_hi = f_hi > fmin ? f_hi : fmin;
+      }
+      const int ro = T.rowoff[r];
+      a = ro + (int)((const volatile CHEM_LDS unsigned short*)bnd)[r * NBND + f_lo];
+      b = ro + (int)((const volatile CHEM_LDS unsigned short*)bnd)[r * NBND + f_hi + 1];
+      b = b < total ? b : total;
+      if (w2 < 0.f) b = a;                                            // the whole row is out of reach
+    };
+    int a_n, b_n;
+    window(0, a_n, b_n);
+#pragma unroll 1
+    for (int dzy = 0; dzy < 9; ++dzy) {
+      const int a = a_n, b = b_n;
+      if (dzy < 8) window(dzy + 1, a_n, b_n);
+      const int r = (lz + dzy / 3) * SY + (ly + dzy % 3);
+      for (int s0 = a & ~3; s0 < b; s0 += 32) {
+        const int len = (b - s0) < 32 ? (b - s0) : 32;
+        const int ng = (len + 3) >> 2;
+        lds_f32x4* gp = (lds_f32x4*)(l3) + 4 * (s0 >> 2);
+        const unsigned int w0 = tmrow[s0 >> 5], w1 = tmrow[(s0 >> 5) + 1];
+        // two groups per trip, ping-pong registers: the reads of the group after next are in flight while one is tested
+        f32x4 X0 = gp[0], Y0 = gp[1], Z0 = gp[2], Q0 = gp[3];
+        unsigned int miss = 0;
+        auto test4 = [&](const f32x4& X, const f32x4& Y, const f32x4& Z, const f32x4& Q) {
+          f32x2 lo = cc - Q.xy, hi = cc - Q.zw;                       // sign bit set at the end: outside
+          lo = __builtin_elementwise_fma(az, Z.xy, lo); hi = __builtin_elementwise_fma(az, Z.zw, hi);
+          lo = __builtin_elementwise_fma(ay, Y.xy, lo); hi = __builtin_elementwise_fma(ay, Y.zw, hi);
+          lo = __builtin_elementwise_fma(ax, X.xy, lo); hi = __builtin_elementwise_fma(ax, X.zw, hi);
+          miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(lo.x), 31);
+          miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(lo.y), 31);
+          miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(hi.x), 31);
+          miss = __builtin_amdgcn_alignbit(miss, __float_as_uint(hi.y), 31);
+        };
+        const int ng2 = (ng + 1) & ~1;                                // (the odd group's bits fall behind `len` and are masked)
+        for (int g = 0; g < ng2; g += 2) {
+          const f32x4 X1 = gp[4], Y1 = gp[5], Z1 = gp[6], Q1 = gp[7];
+          test4(X0, Y0, Z0, Q0);
+          gp += 8;
+          X0 = gp[0]; Y0 = gp[1]; Z0 = gp[2]; Q0 = gp[3];             // (up to two groups past the run: allocated, never used)
+          test4(X1, Y1, Z1, Q1);
+        }
+        unsigned int m = ng2 < 8 ? ~miss << (32 - 4 * ng2) : ~miss;  // candidate u -> bit 31-u
+        m &= ~(len < 32 ? (0xffffffffu >> len) : 0u);                 // slots behind the run
+        m &= 0xffffffffu >> (a > s0 ? a - s0 : 0);                    // slots in front of a run that starts inside a group
+        const int sh = s0 & 31;
+        const unsigned int tm = sh ? __builtin_amdgcn_alignbit(w0, w1, 32 - sh) : w0;   // type-pair filter of these 32 slots
+        const unsigned int ks = (unsigned int)(sself - s0);
+        if (ks < 32u) m &= ~(0x80000000u >> ks);
+        if (ablate == 3) { cnt16 += __popc(m & tm); continue; }
+        if (plain) {
+          // no exclusions (or located as slots) and no int32 row: a hit needs nothing from memory
+          m &= tm;
+          if (fastx) {
+            const unsigned int k0 = (unsigned int)(xs0 - s0), k1 = (unsigned int)(xs1 - s0), k2 = (unsigned int)(xs2 - s0), k3 = (unsigned int)(xs3 - s0);
+            if (k0 < 32u) m &= ~(0x80000000u >> k0);
+            if (k1 < 32u) m &= ~(0x80000000u >> k1);
+            if (k2 < 32u) m &= ~(0x80000000u >> k2);
+            if (k3 < 32u) m &= ~(0x80000000u >> k3);
+          }
+          while (m) {
+            const int k = __clz((int)m);
+            m &= ~(0x80000000u >> k);
+            push((unsigned int)(s0 + k));
+          }
+        } else {
+          while (m) {
+            const int k = __clz((int)m);
+            const unsigned int bit = 0x80000000u >> k;
+            m &= ~bit;
+            const int sl = s0 + k;
+            // global index of the slot from the row's cell tables (this path is rare: int32 rows wanted, or > 4 exclusions)
+            const int e = sl - T.rowoff[r];
+            int kc = 0;
+#pragma unroll
+            for (int qq = 1; qq < SX; ++qq) kc += (e >= T.celloff[r][qq]) ? 1 : 0;
+            const int j = T.cellg[r][kc] + (e - T.celloff[r][kc]);
+            const CHEM_LDS float* cj = img + (sl >> 2) * 16 + (sl & 3);
+            const float ddx = xix - cj[0], ddy = xiy - cj[4], ddz = xiz - cj[8];
+            const bool exact = ddx * ddx + ddy * ddy + ddz * ddz <= rl2;  // difference form: the mask is a superset by the delta shell
+            bool ok = true;
+            if (e1 > e0) {
+              const int tgj = tag[j];
+              for (int ee = e0; ee < e1; ++ee) if (excl_list[ee] == tgj) { ok = false; break; }
+            }
+            if (ok) {
+              if (tm & bit) push((unsigned int)sl);      // (shell pairs included, as on the plain path: the force list does not depend on the path)
+              if (row32 && exact) { if (cnt < S) row32[cnt] = j; ++cnt; }
+            }
+          }
+        }
+      }
+    }
+    // pad the last chunk with the far-away dummy slot (chunks are read whole)
+    const int real16 = cnt16;
+    if (real16 <= S16) while (cnt16 & 7) push((unsigned int)total);
+    nnh[hbase + q] = ablate >= 2 ? (real16 < 0 ? 1 : 0) : (real16 < S16 ? real16 : S16);   // (diagnostic builds of the list leave no usable chunks)
+    if (real16 > S16) atomicMax(&ctl->nl_overflow, real16);
+    if (row32) {
+      const int c32 = cnt < S ? cnt : S;
+      for (int k = c32; k < ((c32 + 3) & ~3); ++k) row32[k] = p;
+      nn[p] = c32;
+      if (cnt > S) atomicMax(&ctl->nl_overflow, cnt);
+    }
+  }
+}
+
 template <typename R, int BS>
 __global__ __launch_bounds__(BS, 6) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
                                                     const TileLDS<R>* __restrict__ desc, R rl2,
                                                     const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
-                                                    ActMask act, int all_active, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
+                                                    ActMask act, int ntypes, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
                                                     int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl) {
   if (!ctl->need_rebuild) return;
   __shared__ TileLDS<R> T;
@@ -1415,11 +1612,18 @@ __global__ __launch_bounds__(BS, 6) void k_nlist_tiles(int ntiles, int CAP, cons
     const int tile = xcd_remap(vb, ntiles);     // gridDim.x is a multiple of 8: vb % 8 == blockIdx.x % 8
     __syncthreads();
     tile_load_desc<R>(T, desc, tile);
+    if constexpr (sizeof(R) == 4) list_stage_clear<BS>(chem_dyn_lds, list_lds_layout(CAP, ntypes), ntypes);
     __syncthreads();
-    if constexpr (sizeof(R) == 4) tile_fill_pairs<BS>(T, reinterpret_cast<float*>(sx), CAP, x4);
-    else tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
-    __syncthreads();
-    dev_nlist_tile<R, BS>(T, sx, tag, rl2, excl_start, excl_list, has_excl, act, nl16, S16, nnh, nlist, S, nn, ctl);
+    if constexpr (sizeof(R) == 4) {
+      const ListLDS L = list_lds_layout(CAP, ntypes);
+      list_stage_f32<BS>(T, chem_dyn_lds, L, CAP, x4, act, ntypes);
+      __syncthreads();
+      dev_nlist_tile_f32<BS>(T, chem_dyn_lds, L, tag, rl2, excl_start, excl_list, has_excl, nl16, S16, nnh, nlist, S, nn, ctl, nullptr, nullptr, x4);
+    } else {
+      tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
+      __syncthreads();
+      dev_nlist_tile<R, BS>(T, sx, tag, rl2, excl_start, excl_list, has_excl, act, nl16, S16, nnh, nlist, S, nn, ctl);
+    }
   }
 }
 
@@ -1474,16 +1678,28 @@ struct UniLJ { float rc2, lj1, lj2, pad; double drc2, dlj1, dlj2; };   // all li
 // exchange is still in flight on the communication stream, and the two boundary tile layers after it.
 struct TileSub { int base1, n1, base2; };
 
+// INTEG instantiation of k_pair_tiles: the velocity-Verlet halves of k_integrate<MODE 3> run in the force kernel's
+// epilogue (second half-kick of this step, first half-kick + drift of the next one) on the lane that owns the home
+// particle -- its pair force never goes through memory.  Positions are double-buffered (every tile still stages the
+// old ones): x4 is read, xn is written, the host swaps the two after the launch.  fb = bonded forces of this step by
+// particle index (k_bonded_work<R, true>; consumed and cleared here), null without bonded terms.
+template <typename R> struct IntegArgs {
+  Vec4<R>* xn; Vec4<R>* v4; const int* tag; Vec4<R>* fb; unsigned long long* blockmax;
+  R dt, cap; int lang; LangevinP<R> lp;
+};
+
 // DIAG = true: diagnostic instantiation with per-block phase stamps (`dbg`) and early exits (`ablate`: 1 stop after
 // staging, 2 skip staging, 3 descriptor only, 4 dispatch only); the production instantiation carries neither.
 // guard != 0: speculative launch of the decomposed path -- leave at once while a rebuild is pending.
-template <typename R, int TPP, bool ENERGY, int BS, int MODE, bool DIAG = false>
+template <typename R, int TPP, bool ENERGY, int BS, int MODE, bool DIAG = false, bool INTEG = false>
 __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
                                                    const TileLDS<R>* __restrict__ desc, const unsigned short* __restrict__ nl16,
                                                    const int* __restrict__ nnh, int S16,
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
                                                    int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
-                                                   double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_) {
+                                                   double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_,
+                                                   IntegArgs<R> ia = IntegArgs<R>{}) {
+  static_assert(!INTEG || (TPP == 1 && !ENERGY && !DIAG), "the integrating epilogue owns one lane per home particle");
   constexpr bool LJONLY = MODE >= 1;
   constexpr int NCH = TPP == 1 ? 3 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
@@ -1530,10 +1746,17 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
   if (DIAG && ablate == 1) return;   // diagnostic: staging only
   if (DIAG && dbg) st2 = wall_clock64();
   double e_lj = 0, e_tab = 0, vir = 0;
+  R d2max = 0;
   for (int q0 = 0; q0 < nhome; q0 += NSL) {
     const int q = q0 + slice;
     R fx = 0, fy = 0, fz = 0;
     if (q0 > 0) { p = -1; if (q < nhome) locate(q); }
+    Vec4<R> vi = mk4<R>(0, 0, 0, 1), fbi = mk4<R>(0, 0, 0, 0);
+    int tgi = 0;
+    if (INTEG && p >= 0) {   // issued in front of the pair loop: their latency hides behind it
+      vi = ia.v4[p]; tgi = ia.tag[p];
+      if (ia.fb) fbi = ia.fb[p];
+    }
     if (p >= 0) {
       const Vec4<R> xi = sx[hslot];
       const int pbase = (int)xi.w * ntypes;
@@ -1569,7 +1792,39 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
 #pragma unroll
       for (int o = TPP / 2; o > 0; o >>= 1) { fx += __shfl_xor(fx, o); fy += __shfl_xor(fy, o); fz += __shfl_xor(fz, o); }
     }
-    if (p >= 0 && sub == 0) f4[p] = mk4<R>(fx, fy, fz, (R)0);
+    if (INTEG) {
+      if (p >= 0) {
+        // same arithmetic, in the same order, as k_integrate<R, 3, LANG, false>
+        Vec4<R> f = mk4<R>(fx + fbi.x, fy + fbi.y, fz + fbi.z, (R)0);
+        if (ia.fb && (fbi.x != (R)0 || fbi.y != (R)0 || fbi.z != (R)0)) ia.fb[p] = mk4<R>(0, 0, 0, 0);
+        if (ia.cap > (R)0) {
+          const R f2 = f.x * f.x + f.y * f.y + f.z * f.z;
+          if (f2 > ia.cap * ia.cap) { const R s = ia.cap / sqrt_r(f2); f.x *= s; f.y *= s; f.z *= s; }
+        }
+        Vec4<R> v = vi;
+        if (ia.lang) langevin_force<R>(ia.lp, tgi, v.w, v.x, v.y, v.z, f.x, f.y, f.z);
+        const R hm = (R)0.5 * ia.dt / v.w;
+        v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z;
+        v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z;
+        Vec4<R> x = sx[hslot];     // home cells carry no periodic shift (and the slab mode never comes here): the staged value is x4[p]
+        const R ddx = ia.dt * v.x, ddy = ia.dt * v.y, ddz = ia.dt * v.z;
+        x.x += ddx; x.y += ddy; x.z += ddz;
+        st_stream(&ia.xn[p], x); st_stream(&ia.v4[p], v);
+        const R dd = ddx * ddx + ddy * ddy + ddz * ddz;
+        d2max = dd > d2max ? dd : d2max;
+      }
+    } else if (p >= 0 && sub == 0) st_stream(&f4[p], mk4<R>(fx, fy, fz, (R)0));
+  }
+  if (INTEG) {
+    __shared__ unsigned long long wm[BS / 64];
+    for (int o = 32; o > 0; o >>= 1) { const R t = __shfl_xor(d2max, o); d2max = t > d2max ? t : d2max; }
+    if (lane_id() == 0) wm[threadIdx.x >> 6] = real_bits(d2max);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = wm[0];
+      for (int k = 1; k < BS / 64; ++k) m = wm[k] > m ? wm[k] : m;
+      ia.blockmax[blockIdx.x] = m;
+    }
   }
   if (DIAG && dbg && threadIdx.x == 0) {   // diagnostic instantiation only: per-block phase stamps (100 MHz wall clock)
     st3 = wall_clock64();
@@ -1802,7 +2057,9 @@ __global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* _
   dev_bonded_prep<256>(i0, n, tag, rtag, bstart, bent, bwork, bj, ctl);
 }
 
-template <typename R>
+// STORE: the bonded force is stored (not added) into a buffer of its own -- the integrating force kernel
+// (k_pair_tiles<..., INTEG>) adds it to the pair force in registers and clears the entry
+template <typename R, bool STORE = false>
 __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int4* __restrict__ bwork, const int4* __restrict__ bj,
                                                      const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl, int guard, BTab bt) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1818,6 +2075,7 @@ __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__
     if (bp.arity == 4) { j3 = bj[e + 1].x; ++e; }
     bonded_term<R, false>(bp, me, jj.x, jj.y, bp.arity > 2 ? jj.z : 0, j3, x4, box, f, nullptr, ctl, bt);
   }
+  if (STORE) { f4[wk.x] = mk4<R>((R)f.x, (R)f.y, (R)f.z, (R)0); return; }
   Vec4<R> fo = f4[wk.x];
   fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;
   f4[wk.x] = fo;
@@ -1878,7 +2136,7 @@ __device__ __forceinline__ bool grid_barrier(GridBar* gb, DevCtl* ctl) {
 }
 
 template <typename R> struct FusedArgs {
-  int n, ncell, ntiles, CAP, S, has_excl, criterion, par, seg_shift, tseg_shift, nblk, want32;
+  int n, ncell, ntiles, CAP, S, has_excl, criterion, par, seg_shift, tseg_shift, nblk, want32, ntypes, ablate;
   double half_skin; R rl2;
   Vec4<R> *x4, *v4, *x4o, *v4o, *x0;
   int *tag, *tago, *rtag; int4 *img4, *img4o;
@@ -1888,6 +2146,7 @@ template <typename R> struct FusedArgs {
   unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
   const int* bstart; const BondedEntry* bent; int4 *bwork, *bj; int nbent;
   Box<R> box; ActMask act;
+  long long* wgst;   // diagnostics (option debug_stamps=2): 8 wall-clock stamps per workgroup of the last rebuilding launch
 };
 
 // segment offsets: s_off[k] = base + sum of tot[0..k), s_off[nseg] = grand total (nseg <= 1024)
@@ -1927,8 +2186,11 @@ __device__ __forceinline__ void seg_scan(int* cnt, int nitem, int shift, int* lo
   }
 }
 
+#ifndef CHEM_FUSED_WAVES
+#define CHEM_FUSED_WAVES 4
+#endif
 template <typename R, int BS>
-__global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
+__global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const FusedArgs<R> a) {
   __shared__ TileLDS<R> T;
   __shared__ int s_off[1025];
   __shared__ unsigned long long s_m[BS / 64];
@@ -1957,10 +2219,14 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
   // ---- P1: bin.  Members go straight into the bucket row of their cell; per-segment particle totals are
   //          accumulated beside the cell counts, so that no scan phase is needed afterwards ----
   if (b == 0 && t == 0) a.gb->stamp[0] = wall_clock64();
+  long long* const wst = a.wgst ? a.wgst + 8 * (size_t)b : nullptr;
+#define WGST(K) do { if (wst && t == 0) wst[K] = wall_clock64(); } while (0)
+  WGST(0);
   if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
   if (b == 0 && t == 8) ctl->bwork_count = 0;
   { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl, a.bucket, a.bcap, a.btot, a.seg_shift); }
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) { const long long st = wall_clock64(); a.gb->stamp[1] = st; a.gb->stamp[2] = st; a.gb->stamp[3] = st; }
+  WGST(1);
+  if (!grid_barrier(a.gb, ctl)) return; WGST(2); if (b == 0 && t == 0) { const long long st = wall_clock64(); a.gb->stamp[1] = st; a.gb->stamp[2] = st; a.gb->stamp[3] = st; }
   if (ctl->bucket_overflow) {
     // a cell is fuller than a bucket row: nothing but the counters has been touched yet -- clear them and leave; the
     // host redoes this rebuild with the unfused chain (force_rebuild stays set)
@@ -1996,7 +2262,8 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
       a.tn[tile] = nh;
     }
   }
-  if (!grid_barrier(a.gb, ctl)) return; if (b == 0 && t == 0) { const long long st = wall_clock64(); a.gb->stamp[4] = st; a.gb->stamp[5] = st; }
+  WGST(3);
+  if (!grid_barrier(a.gb, ctl)) return; WGST(4); if (b == 0 && t == 0) { const long long st = wall_clock64(); a.gb->stamp[4] = st; a.gb->stamp[5] = st; }
 
   // ---- P6: tile descriptors + list build.  Tiles are handed out dynamically, each XCD first drains its own contiguous
   //          range of tiles (L2 locality, see xcd_remap) and then helps the others.  The counts of this rebuild are
@@ -2023,27 +2290,38 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
     }
     if (a.nbent > 0) dev_bonded_prep<BS>(0, a.n, a.tago, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl);   // rtag is complete since the last barrier
     const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
+    int ndone = 0;
+    WGST(5);
+    // thread 0 claims a tile: own XCD's queue first, then the others'
+    auto claim = [&]() {
+      int tile = -1;
+      for (int d = 0; d < 8 && tile < 0; ++d) {
+        const int x = (myx + d) & 7;
+        const int cntx = q + (x < r ? 1 : 0);
+        if (__hip_atomic_load(&a.gb->tq[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)cntx) continue;
+        const int k = (int)atomicAdd(&a.gb->tq[x][0], 1u);
+        if (k < cntx) tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+      }
+      return tile;
+    };
     for (;;) {
       __syncthreads();
-      if (t == 0) {
-        int tile = -1;
-        for (int d = 0; d < 8 && tile < 0; ++d) {
-          const int x = (myx + d) & 7;
-          const int cntx = q + (x < r ? 1 : 0);
-          if (__hip_atomic_load(&a.gb->tq[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)cntx) continue;
-          const int k = (int)atomicAdd(&a.gb->tq[x][0], 1u);
-          if (k < cntx) tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
-        }
-        s_tile = tile;
-      }
-      __syncthreads();
+      if (t == 0) s_tile = claim();    // (claiming ahead of time, beside the previous tile's work, hides this round trip but
+      __syncthreads();                 //  unbalances the tail of the phase: measured 307 -> 367 us)
       const int tile = s_tile;
       if (tile < 0) break;
+      ++ndone;
+      // base of the tile's list region = prefix of its segment + the home counts of the tiles in front of it inside the
+      // segment: loaded here by the last wave, reduced after the tables (their latency overlaps)
+      int hb_part = 0;
+      if (w == BS / 64 - 1) {
+        for (int j = ((tile >> a.tseg_shift) << a.tseg_shift) + lane; j < tile; j += 64) hb_part += a.tn[j];
+      }
+      if constexpr (sizeof(R) == 4) list_stage_clear<BS>(chem_dyn_lds, list_lds_layout(a.CAP, a.ntypes), a.ntypes);   // (tile_tables synchronises)
       tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl, a.cell_sub);      // ends with a workgroup barrier
-      if (t == 0) {
-        int hb = s_off[tile >> a.tseg_shift];
-        for (int j = (tile >> a.tseg_shift) << a.tseg_shift; j < tile; ++j) hb += a.tn[j];
-        T.geom[5] = hb;
+      if (w == BS / 64 - 1) {
+        for (int o = 32; o > 0; o >>= 1) hb_part += __shfl_xor(hb_part, o);
+        if (lane == 0) T.geom[5] = s_off[tile >> a.tseg_shift] + hb_part;
       }
       __syncthreads();
       {   // the descriptor every force launch until the next rebuild reads
@@ -2051,12 +2329,23 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
         int* dst = reinterpret_cast<int*>(&a.desc[tile]);
         for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
       }
-      if constexpr (sizeof(R) == 4) tile_fill_pairs<BS>(T, reinterpret_cast<float*>(sx), a.CAP, a.x4o);
-      else tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
-      __syncthreads();
-      dev_nlist_tile<R, BS>(T, sx, a.tago, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
-                            a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o);
+      if constexpr (sizeof(R) == 4) {
+        const ListLDS L = list_lds_layout(a.CAP, a.ntypes);
+        list_stage_f32<BS>(T, chem_dyn_lds, L, a.CAP, a.x4o, a.act, a.ntypes);
+        __syncthreads();
+        if (a.ablate == 1) { for (int q = t; q < T.geom[4]; q += BS) a.nnh[T.geom[5] + q] = 0; }
+        else
+        dev_nlist_tile_f32<BS>(T, chem_dyn_lds, L, a.tago, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.nl16, a.S, a.nnh,
+                               a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, a.ablate);
+      } else {
+        tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
+        __syncthreads();
+        dev_nlist_tile<R, BS>(T, sx, a.tago, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
+                              a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o);
+      }
     }
+    WGST(6);
+    if (wst && t == 0) wst[7] = ndone;
     // copy-back (+ reference positions): every workgroup moves its share once it has no tile left
     for (int k = b * BS + t; k < a.n; k += NB * BS) {
       const Vec4<R> xk = a.x4o[k];
@@ -2065,6 +2354,8 @@ __global__ __launch_bounds__(BS, 6) void k_rebuild_fused(const FusedArgs<R> a) {
     }
   }
   if (b == 0 && t == 0) a.gb->stamp[6] = wall_clock64();
+  if (wst) { __syncthreads(); if (t == 0) wst[7] |= (long long)(wall_clock64() - wst[0]) << 16; }
+#undef WGST
 }
 
 // =======================================================================================
