@@ -340,6 +340,7 @@ template <typename R> struct CtxT : Ctx {
     cell_n.alloc(box.ncell + 1);
     bcap = 64;
     bucket.alloc((size_t)box.ncell * bcap);
+    HIPCHK(hipMemsetAsync(bucket.p, 0, sizeof(int) * (size_t)box.ncell * bcap, stream));   // (the sort phase reads whole rows: entries must always be valid indices)
     if (!gbar.p) { gbar.alloc(1); HIPCHK(hipMemsetAsync(gbar.p, 0, sizeof(GridBar), stream)); }
     HIPCHK(hipMemsetAsync(seg_tot.p, 0, sizeof(int) * 1024, stream));
     use_fused = true;

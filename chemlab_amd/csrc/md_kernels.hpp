@@ -274,80 +274,106 @@ template <typename R>
 __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R>* v4, const int* tag, int4* img4, const Box<R>& box,
                                         int* cell_cnt, int* cell_of, int* slot_of, const MigBuf<R>& mdn, const MigBuf<R>& mup, DevCtl* ctl,
                                         int* bucket = nullptr, int bcap = 0, int* seg_tot = nullptr, int seg_shift = 0) {
-  // the loop bound is wave-uniform (rounded up) because the slot assignment below uses cross-lane ops
+  // Four particles per thread and trip, in three stages -- all position loads, then all slot atomics, then the stores --
+  // so that a thread waits for ONE load and ONE returning atomic round trip per four particles instead of one each per
+  // particle (the phase is a chain of dependent device-scope round trips, not bandwidth).
+  // The trip bound is wave-uniform (rounded up) because the slot assignment uses cross-lane ops.
+  constexpr int U = 4;
   const int iend = i0 + n;
-  for (int ib = i0 + blockIdx.x * blockDim.x; ib < iend; ib += gridDim.x * blockDim.x) {
-    const int i = ib + threadIdx.x;
-    int cid = -1;                       // -1: lane idle or particle migrates away
-    if (i < iend) {
-      Vec4<R> x = x4[i];
-      int4 im = img4[i];
-      R* p = &x.x; int* ip = &im.x;
-      int c[3];
-      bool moved = false;   // folded back into the box: only then position and image counters are written back
+  const int G = gridDim.x * blockDim.x;
+  const int lane = lane_id();
+  for (int ib0 = i0 + blockIdx.x * blockDim.x; ib0 < iend; ib0 += U * G) {
+    Vec4<R> xs[U]; int4 ims[U];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        R s = floor_r(p[d] * box.invL[d]);
-        if (s != (R)0) { p[d] -= s * box.L[d]; ip[d] += (int)s; moved = true; }
-        if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; moved = true; }
-        if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; moved = true; }
-        int cc = (int)(p[d] * box.cell_inv[d]);
-        int ncd = (d == 2 && box.zghost) ? box.nzg : (box.nc[d] > 0 ? box.nc[d] : 1);
-        cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
-        c[d] = cc;
+    for (int u = 0; u < U; ++u) {
+      const int i = ib0 + u * G + (int)threadIdx.x;
+      if (i < iend) { xs[u] = x4[i]; ims[u] = img4[i]; }
+    }
+    int cids[U], bases[U], starts[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = ib0 + u * G + (int)threadIdx.x;
+      int cid = -1;                       // -1: lane idle or particle migrates away
+      if (i < iend) {
+        Vec4<R> x = xs[u];
+        int4 im = ims[u];
+        R* p = &x.x; int* ip = &im.x;
+        int c[3];
+        bool moved = false;   // folded back into the box: only then position and image counters are written back
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          R s_ = floor_r(p[d] * box.invL[d]);
+          if (s_ != (R)0) { p[d] -= s_ * box.L[d]; ip[d] += (int)s_; moved = true; }
+          if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; moved = true; }
+          if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; moved = true; }
+          int cc = (int)(p[d] * box.cell_inv[d]);
+          int ncd = (d == 2 && box.zghost) ? box.nzg : (box.nc[d] > 0 ? box.nc[d] : 1);
+          cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
+          c[d] = cc;
+        }
+        int dir = 0;   // 0 stays, -1 leaves downwards, +1 upwards
+        if (box.zghost) {
+          // c[2] is the global layer of the folded z; the slab owns layers [z0g, z0g + own)
+          const int own = box.nc[2] - 2, gz = c[2];
+          const int gu = (box.z0g + own) % box.nzg, gd = (box.z0g - 1 + box.nzg) % box.nzg;
+          if (gz >= box.z0g && gz < box.z0g + own) c[2] = gz - box.z0g + 1;
+          else if (gz == gu) dir = 1;
+          else if (gz == gd) dir = -1;
+          else { ctl->mig_error = 1; c[2] = 1; }   // moved by more than one layer: impossible within skin/2
+        }
+        if (moved) { x4[i] = x; img4[i] = im; }
+        if (dir) {
+          const MigBuf<R>& mb = dir < 0 ? mdn : mup;
+          const int k = atomicAdd(mb.count, 1);
+          if (k < mb.cap) { mb.x[k] = x; mb.v[k] = v4[i]; mb.img[k] = im; mb.tag[k] = tag[i]; } else ctl->mig_error = 2;
+          cell_of[i] = -1;
+        } else {
+          cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
+          if (!bucket) cell_of[i] = cid;
+        }
       }
-      int dir = 0;   // 0 stays, -1 leaves downwards, +1 upwards
-      if (box.zghost) {
-        // c[2] is the global layer of the folded z; the slab owns layers [z0g, z0g + own)
-        const int own = box.nc[2] - 2, gz = c[2];
-        const int gu = (box.z0g + own) % box.nzg, gd = (box.z0g - 1 + box.nzg) % box.nzg;
-        if (gz >= box.z0g && gz < box.z0g + own) c[2] = gz - box.z0g + 1;
-        else if (gz == gu) dir = 1;
-        else if (gz == gd) dir = -1;
-        else { ctl->mig_error = 1; c[2] = 1; }   // moved by more than one layer: impossible within skin/2
-      }
-      if (moved) { x4[i] = x; img4[i] = im; }
-      if (dir) {
-        const MigBuf<R>& mb = dir < 0 ? mdn : mup;
-        const int k = atomicAdd(mb.count, 1);
-        if (k < mb.cap) { mb.x[k] = x; mb.v[k] = v4[i]; mb.img[k] = im; mb.tag[k] = tag[i]; } else ctl->mig_error = 2;
-        cell_of[i] = -1;
-      } else {
-        cid = box.nc[0] > 0 ? (c[2] * box.nc[1] + c[1]) * box.nc[0] + c[0] : 0;
-        if (!bucket) cell_of[i] = cid;
-      }
+      cids[u] = cid;
     }
     // Slot inside the cell.  The arrays are still in the cell order of the previous rebuild, so
     // neighbouring lanes mostly share a cell: one atomic per run of equal cells in the wave
     // (run head adds the run length, the others take base + rank) instead of one per particle --
     // ~18 same-address atomics per cell were the whole cost of this kernel.
-    const int lane = lane_id();
-    const int prev = __shfl_up(cid, 1);
-    const bool head = lane == 0 || prev != cid;
-    const unsigned long long hm = __ballot(head);
-    const unsigned long long upto = hm & (~0ull >> (63 - lane));          // heads at lanes <= lane
-    const int start = 63 - __clzll((long long)upto);
-    const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
-    const int end = above ? lane + __ffsll((long long)above) : 64;        // first head after this lane
-    int base = 0;
-    if (head && cid >= 0) base = atomicAdd(&cell_cnt[cid], end - start);
-    if (seg_tot) {
-      // particles per segment of 2^seg_shift cells (fused rebuild): one atomic per run of equal SEGMENTS in the wave
-      // (a wave usually sits inside one segment; per-cell-run atomics on the same word serialise in the L2)
-      const int sg = cid >= 0 ? cid >> seg_shift : -1;
-      const int sprev = __shfl_up(sg, 1);
-      const bool shead = lane == 0 || sprev != sg;
-      const unsigned long long shm = __ballot(shead);
-      const unsigned long long sabove = lane == 63 ? 0ull : (shm >> (lane + 1));
-      const int send = sabove ? lane + __ffsll((long long)sabove) : 64;
-      if (shead && sg >= 0) atomicAdd(&seg_tot[sg], send - lane);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cid = cids[u];
+      const int prev = __shfl_up(cid, 1);
+      const bool head = lane == 0 || prev != cid;
+      const unsigned long long hm = __ballot(head);
+      const unsigned long long upto = hm & (~0ull >> (63 - lane));          // heads at lanes <= lane
+      const int start = 63 - __clzll((long long)upto);
+      const unsigned long long above = lane == 63 ? 0ull : (hm >> (lane + 1));
+      const int end = above ? lane + __ffsll((long long)above) : 64;        // first head after this lane
+      int base = 0;
+      if (head && cid >= 0) base = atomicAdd(&cell_cnt[cid], end - start);
+      bases[u] = base; starts[u] = start;
+      if (seg_tot) {
+        // particles per segment of 2^seg_shift cells (fused rebuild): one atomic per run of equal SEGMENTS in the wave
+        // (a wave usually sits inside one segment; per-cell-run atomics on the same word serialise in the L2)
+        const int sg = cid >= 0 ? cid >> seg_shift : -1;
+        const int sprev = __shfl_up(sg, 1);
+        const bool shead = lane == 0 || sprev != sg;
+        const unsigned long long shm = __ballot(shead);
+        const unsigned long long sabove = lane == 63 ? 0ull : (shm >> (lane + 1));
+        const int send = sabove ? lane + __ffsll((long long)sabove) : 64;
+        if (shead && sg >= 0) atomicAdd(&seg_tot[sg], send - lane);
+      }
     }
-    base = __shfl(base, start);
-    if (cid >= 0) {
-      const int slot = base + (lane - start);
-      if (!bucket) slot_of[i] = slot;
-      else if (slot < bcap) bucket[(size_t)cid * bcap + slot] = i;
-      else atomicMax(&ctl->bucket_overflow, slot + 1);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = ib0 + u * G + (int)threadIdx.x;
+      const int cid = cids[u];
+      const int base = __shfl(bases[u], starts[u]);
+      if (cid >= 0) {
+        const int slot = base + (lane - starts[u]);
+        if (!bucket) slot_of[i] = slot;
+        else if (slot < bcap) bucket[(size_t)cid * bcap + slot] = i;
+        else atomicMax(&ctl->bucket_overflow, slot + 1);
+      }
     }
   }
 }
