@@ -131,8 +131,7 @@ struct Ctx {
   int opt_time_pair = 0;    // HIP-event timing of every N-th pair-force launch (0 = off)
   int64_t pair_launch_no = 0;
   int opt_fuse = 1;         // fused integrate2+integrate1
-  int opt_fuse_pair = 0;
-  int opt_ablate_list = 0;  // diagnostics (with debug_stamps): parts of the list build left out, see tools/rebuild_stamps.py    // ... and both in the force kernel's epilogue (k_pair_tiles INTEG)
+  int opt_ablate_list = 0;  // diagnostics (with debug_stamps): parts of the list build left out, see tools/rebuild_stamps.py
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
   int opt_fused = 1;        // rebuild chain as one persistent launch with grid barriers (single domain, tiles)
   int pair_guard = 0;       // 256 while the force kernels are launched speculatively (decomposed path)
@@ -228,8 +227,6 @@ template <typename R> struct CtxT : Ctx {
   DBuf<PairCore<R>> pcore; DBuf<PairExt<R>> pext;
   DBuf<DevCtl> ctl;
   DBuf<unsigned long long> blockmax;
-  DBuf<V4> x4n, fbond;      // second position buffer / bonded forces of the step (integrating force kernel)
-  int maxima_n = 0;         // entries of blockmax the last drift wrote (k_integrate blocks, or tiles)
   DBuf<double> eout, ekout, elist;
   // reactions
   DBuf<Candidate> cand, evout; int cand_cap = 0;
@@ -348,7 +345,7 @@ template <typename R> struct CtxT : Ctx {
   void launch_rebuild_fused() {
     FusedArgs<R> a{};
     a.n = n; a.ncell = box.ncell; a.ntiles = ntiles; a.CAP = tile_cap; a.S = S; a.has_excl = has_excl; a.criterion = opt_criterion;
-    a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = maxima_n; a.want32 = want32 ? 1 : 0; a.ntypes = ntypes; a.ablate = dbg_on ? opt_ablate_list : 0;
+    a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = cdiv(n, kIntPerBlock); a.want32 = want32 ? 1 : 0; a.ntypes = ntypes; a.ablate = dbg_on ? opt_ablate_list : 0;
     a.half_skin = 0.5 * skin; a.rl2 = (R)((rc + skin) * (rc + skin));
     a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
@@ -371,7 +368,6 @@ template <typename R> struct CtxT : Ctx {
                       if (T == 1 && !E) SETA((k_pair_tiles<R, 1, false, 512, M, true>))
 #define SETT(E, M) SETB(1, E, M); SETB(2, E, M); SETB(4, E, M); SETB(8, E, M)
     SETT(false, 2); SETT(false, 1); SETT(false, 0); SETT(true, 0);
-    SETA((k_pair_tiles<R, 1, false, 512, 2, false, true>)); SETA((k_pair_tiles<R, 1, false, 512, 1, false, true>)); SETA((k_pair_tiles<R, 1, false, 512, 0, false, true>));
 #undef SETT
 #undef SETB
 #undef SETA
@@ -434,9 +430,6 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipMemsetAsync(nn.p, 0, sizeof(int) * ac, stream));
     ctl.alloc(1);
     HIPCHK(hipMemsetAsync(ctl.p, 0, sizeof(DevCtl), stream));
-    x4n.alloc(x4.n); fbond.alloc(ac);
-    HIPCHK(hipMemsetAsync(fbond.p, 0, sizeof(V4) * ac, stream));
-    maxima_n = cdiv(n, kIntPerBlock);
     blockmax.alloc(cdiv(ac, 256));
     HIPCHK(hipMemsetAsync(blockmax.p, 0, sizeof(unsigned long long) * cdiv(ac, 256), stream));
     eout.alloc(3 * (size_t)cdiv((long long)ac * 64, 256) + 8);
@@ -735,7 +728,7 @@ template <typename R> struct CtxT : Ctx {
 
   void decide_and_rebuild() {
     if (use_fused) { tbeg(1); launch_rebuild_fused(); tend(); return; }
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, maxima_n, 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, kIntPerBlock), 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
     launch_rebuild_chain();
   }
 
@@ -987,39 +980,6 @@ template <typename R> struct CtxT : Ctx {
     pair_guard = 0;
   }
 
-  // Force evaluation of step `istep` with the integrator halves in the force kernel's epilogue (k_pair_tiles INTEG):
-  // bonded forces first, into their own buffer; positions of the next step go to the second buffer, swapped here.
-  bool can_fuse_pair() const {
-    return opt_fuse_pair && opt_fuse && use_tiles && use_fused && !dd_on && !opt_criterion && !resc_kind && !dbg_on && !opt_ablate &&
-           pair_bs == 512 && pick_tpp() == 1 && ntiles <= (int)blockmax.n && G == 0;
-  }
-  void compute_forces_integrate(int64_t istep) {
-    const bool timed = timed_step;
-    const bool bonded = nbent > 0;
-    if (bonded) {
-      if (bwork_dirty) {
-        HIPCHK(hipMemsetAsync(&ctl.p->bwork_count, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
-        bwork_dirty = false;
-      }
-      if (timed) tbeg(3);
-      hipLaunchKernelGGL((k_bonded_work<R, true>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, fbond.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, 0, btab_view());
-      if (timed) tend();
-    }
-    IntegArgs<R> ia{};
-    ia.xn = x4n.p; ia.v4 = v4.p; ia.tag = tag.p; ia.fb = bonded ? fbond.p : (V4*)nullptr; ia.blockmax = blockmax.p;
-    ia.dt = (R)dt; ia.cap = cap_force > 0 ? (R)cap_force : (R)0; ia.lang = lang ? 1 : 0; ia.lp = lang_params(istep, 1);
-    const TileSub ts{0, ntiles, 0};
-    if (timed) tbeg(0);
-#define LPI(M) hipLaunchKernelGGL((k_pair_tiles<R, 1, false, 512, M, false, true>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, f4.p, tdesc.p, \
-                                  nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, 0.5 * skin, ctl.p, 0, 0, (long long*)nullptr, ts, ia)
-    if (uniform_lj) LPI(2); else if (lj_only) LPI(1); else LPI(0);
-#undef LPI
-    if (timed) tend();
-    std::swap(x4.p, x4n.p);
-    maxima_n = ntiles;
-  }
-
   LangevinP<R> lang_params(int64_t istep, int phase) const {
     LangevinP<R> lp{};
     lp.on = lang ? 1 : 0; lp.kT = kT; lp.gamma = gamma; lp.dt = dt; lp.seed = lang_seed; lp.step = (uint64_t)istep; lp.phase = (uint32_t)phase;
@@ -1028,7 +988,6 @@ template <typename R> struct CtxT : Ctx {
 
   template <int MODE> void launch_integrate(bool with_lang, bool storef, int64_t istep, int phase) {
     const int nb = cdiv(n, kIntPerBlock);
-    if (MODE & 2) maxima_n = nb;
     LangevinP<R> lp = lang_params(istep, phase);
     // CapForce acts on the freshly evaluated conservative force: every launch that applies the thermostat
     // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
@@ -1161,14 +1120,11 @@ template <typename R> struct CtxT : Ctx {
       timed_step = opt_time_pair && (pair_launch_no++ % opt_time_pair) == 0;
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
       const bool last = (s == nsteps - 1);
-      const bool split = last || react_due || !opt_fuse || resc_kind;   // this step ends with a half-kick of its own
-      const bool fuse_pair = !split && can_fuse_pair();
       if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
-      else { decide_and_rebuild(); if (fuse_pair) compute_forces_integrate(step); else compute_forces(); }
+      else { decide_and_rebuild(); compute_forces(); }
       resort = false;   // a rebuild requested by the last reaction step (force_rebuild on the device) has happened by now
 
-      if (fuse_pair) ++step;
-      else if (split) {
+      if (last || react_due || !opt_fuse || resc_kind) {
         launch_integrate<1>(lang, lang, step, 1);
         ++step;
         if (resc_kind == 1 || resc_kind == 3 || (resc_kind == 2 && step % (int64_t)resc_param == 0)) rescale_velocities();
@@ -2108,7 +2064,6 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   if (k == "tpp") { const int v = (int)value; REQUIRE(v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64, CHEM_EINVAL, "tpp must be a power of two <= 64"); CTX.opt_tpp = v; }
   else if (k == "time_pair_kernel") CTX.opt_time_pair = value > 0 ? (int)value : 0;
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
-  else if (k == "fuse_pair_integrate") CTX.opt_fuse_pair = value != 0;
   else if (k == "ablate_list") CTX.opt_ablate_list = (int)value;
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else if (k == "fused_rebuild") { CTX.opt_fused = value != 0; CTX.geom_dirty = true; }

@@ -1692,28 +1692,16 @@ struct UniLJ { float rc2, lj1, lj2, pad; double drc2, dlj1, dlj2; };   // all li
 // exchange is still in flight on the communication stream, and the two boundary tile layers after it.
 struct TileSub { int base1, n1, base2; };
 
-// INTEG instantiation of k_pair_tiles: the velocity-Verlet halves of k_integrate<MODE 3> run in the force kernel's
-// epilogue (second half-kick of this step, first half-kick + drift of the next one) on the lane that owns the home
-// particle -- its pair force never goes through memory.  Positions are double-buffered (every tile still stages the
-// old ones): x4 is read, xn is written, the host swaps the two after the launch.  fb = bonded forces of this step by
-// particle index (k_bonded_work<R, true>; consumed and cleared here), null without bonded terms.
-template <typename R> struct IntegArgs {
-  Vec4<R>* xn; Vec4<R>* v4; const int* tag; Vec4<R>* fb; unsigned long long* blockmax;
-  R dt, cap; int lang; LangevinP<R> lp;
-};
-
 // DIAG = true: diagnostic instantiation with per-block phase stamps (`dbg`) and early exits (`ablate`: 1 stop after
 // staging, 2 skip staging, 3 descriptor only, 4 dispatch only); the production instantiation carries neither.
 // guard != 0: speculative launch of the decomposed path -- leave at once while a rebuild is pending.
-template <typename R, int TPP, bool ENERGY, int BS, int MODE, bool DIAG = false, bool INTEG = false>
+template <typename R, int TPP, bool ENERGY, int BS, int MODE, bool DIAG = false>
 __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
                                                    const TileLDS<R>* __restrict__ desc, const unsigned short* __restrict__ nl16,
                                                    const int* __restrict__ nnh, int S16,
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
                                                    int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
-                                                   double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_,
-                                                   IntegArgs<R> ia = IntegArgs<R>{}) {
-  static_assert(!INTEG || (TPP == 1 && !ENERGY && !DIAG), "the integrating epilogue owns one lane per home particle");
+                                                   double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_) {
   constexpr bool LJONLY = MODE >= 1;
   constexpr int NCH = TPP == 1 ? 3 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
@@ -1760,17 +1748,10 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
   if (DIAG && ablate == 1) return;   // diagnostic: staging only
   if (DIAG && dbg) st2 = wall_clock64();
   double e_lj = 0, e_tab = 0, vir = 0;
-  R d2max = 0;
   for (int q0 = 0; q0 < nhome; q0 += NSL) {
     const int q = q0 + slice;
     R fx = 0, fy = 0, fz = 0;
     if (q0 > 0) { p = -1; if (q < nhome) locate(q); }
-    Vec4<R> vi = mk4<R>(0, 0, 0, 1), fbi = mk4<R>(0, 0, 0, 0);
-    int tgi = 0;
-    if (INTEG && p >= 0) {   // issued in front of the pair loop: their latency hides behind it
-      vi = ia.v4[p]; tgi = ia.tag[p];
-      if (ia.fb) fbi = ia.fb[p];
-    }
     if (p >= 0) {
       const Vec4<R> xi = sx[hslot];
       const int pbase = (int)xi.w * ntypes;
@@ -1806,39 +1787,7 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
 #pragma unroll
       for (int o = TPP / 2; o > 0; o >>= 1) { fx += __shfl_xor(fx, o); fy += __shfl_xor(fy, o); fz += __shfl_xor(fz, o); }
     }
-    if (INTEG) {
-      if (p >= 0) {
-        // same arithmetic, in the same order, as k_integrate<R, 3, LANG, false>
-        Vec4<R> f = mk4<R>(fx + fbi.x, fy + fbi.y, fz + fbi.z, (R)0);
-        if (ia.fb && (fbi.x != (R)0 || fbi.y != (R)0 || fbi.z != (R)0)) ia.fb[p] = mk4<R>(0, 0, 0, 0);
-        if (ia.cap > (R)0) {
-          const R f2 = f.x * f.x + f.y * f.y + f.z * f.z;
-          if (f2 > ia.cap * ia.cap) { const R s = ia.cap / sqrt_r(f2); f.x *= s; f.y *= s; f.z *= s; }
-        }
-        Vec4<R> v = vi;
-        if (ia.lang) langevin_force<R>(ia.lp, tgi, v.w, v.x, v.y, v.z, f.x, f.y, f.z);
-        const R hm = (R)0.5 * ia.dt / v.w;
-        v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z;
-        v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z;
-        Vec4<R> x = sx[hslot];     // home cells carry no periodic shift (and the slab mode never comes here): the staged value is x4[p]
-        const R ddx = ia.dt * v.x, ddy = ia.dt * v.y, ddz = ia.dt * v.z;
-        x.x += ddx; x.y += ddy; x.z += ddz;
-        ia.xn[p] = x; ia.v4[p] = v;
-        const R dd = ddx * ddx + ddy * ddy + ddz * ddz;
-        d2max = dd > d2max ? dd : d2max;
-      }
-    } else if (p >= 0 && sub == 0) f4[p] = mk4<R>(fx, fy, fz, (R)0);
-  }
-  if (INTEG) {
-    __shared__ unsigned long long wm[BS / 64];
-    for (int o = 32; o > 0; o >>= 1) { const R t = __shfl_xor(d2max, o); d2max = t > d2max ? t : d2max; }
-    if (lane_id() == 0) wm[threadIdx.x >> 6] = real_bits(d2max);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      unsigned long long m = wm[0];
-      for (int k = 1; k < BS / 64; ++k) m = wm[k] > m ? wm[k] : m;
-      ia.blockmax[blockIdx.x] = m;
-    }
+    if (p >= 0 && sub == 0) f4[p] = mk4<R>(fx, fy, fz, (R)0);
   }
   if (DIAG && dbg && threadIdx.x == 0) {   // diagnostic instantiation only: per-block phase stamps (100 MHz wall clock)
     st3 = wall_clock64();
@@ -2071,9 +2020,7 @@ __global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* _
   dev_bonded_prep<256>(i0, n, tag, rtag, bstart, bent, bwork, bj, ctl);
 }
 
-// STORE: the bonded force is stored (not added) into a buffer of its own -- the integrating force kernel
-// (k_pair_tiles<..., INTEG>) adds it to the pair force in registers and clears the entry
-template <typename R, bool STORE = false>
+template <typename R>
 __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int4* __restrict__ bwork, const int4* __restrict__ bj,
                                                      const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl, int guard, BTab bt) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2089,7 +2036,6 @@ __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__
     if (bp.arity == 4) { j3 = bj[e + 1].x; ++e; }
     bonded_term<R, false>(bp, me, jj.x, jj.y, bp.arity > 2 ? jj.z : 0, j3, x4, box, f, nullptr, ctl, bt);
   }
-  if (STORE) { f4[wk.x] = mk4<R>((R)f.x, (R)f.y, (R)f.z, (R)0); return; }
   Vec4<R> fo = f4[wk.x];
   fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;
   f4[wk.x] = fo;

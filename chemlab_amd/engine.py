@@ -229,6 +229,16 @@ class Engine:
             self._ck(self.api.get_verlet_pairs(self.ctx, _ptr(out, C.c_int64), n))
         return out
 
+    def debug_force_list(self, tag):
+        """Diagnostic (tests): partner tags of the 16-bit force list of particle `tag`, in list order."""
+        lib = self.api.lib
+        lib.chem_debug_force_list.restype = C.c_int64
+        buf = np.zeros(1024, dtype=np.int32)
+        m = lib.chem_debug_force_list(C.c_void_p(self.ctx), C.c_int32(int(tag)), buf.ctypes.data_as(C.c_void_p), C.c_int64(buf.size))
+        if m < 0:
+            raise ChemError(int(m), "force list not available (no LDS tiles)")
+        return buf[:m].copy()
+
     def observe(self):
         o = _capi.Obs()
         self._ck(self.api.observe(self.ctx, C.byref(o)))

@@ -1043,3 +1043,37 @@ def test_excluded_pairs_are_not_reaction_candidates(make_gpu, make_oracle):
     pairs = [(min(e[1], e[2]), max(e[1], e[2])) for e in eo]
     assert len(pairs) == len(set(pairs))             # no pair reacted twice
     assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+
+
+def test_force_list_is_a_thin_superset_of_the_exact_list(make_gpu, make_oracle):
+    """fp32 list build: the expanded-form distance test admits a shell of ~5e-5 beyond rc+skin (DESIGN.md, list build);
+    the 16-bit force list must contain every active, non-excluded pair of the oracle's Verlet list and nothing
+    farther out than that shell.  (Types: reactive_melt switches the A-B and A-D potentials off.)"""
+    spec = W.reactive_melt(n=8788, seed=13)
+    g, o, _ = both(make_gpu, make_oracle, spec, 32, thermostat=False, reactions=False)
+    g.run(0); o.run(0)
+    pos = o.get_state("POS"); L = np.array(spec["box"]); rl = spec["rc"] + spec["skin"]
+    typ = o.get_state("TYPE").astype(int).ravel()
+    pairs = o.get_verlet_pairs() - 1      # particle ids (1..n here) -> tags
+    assert pairs.min() == 0
+    nb = {}
+    for a, b in pairs.tolist():
+        nb.setdefault(a, set()).add(b); nb.setdefault(b, set()).add(a)
+    f_ref = o.get_state("FORCE")
+    checked = 0
+    for tag in range(0, spec["n"], 97):
+        lst = g.debug_force_list(tag)
+        assert len(set(lst.tolist())) == len(lst)
+        d = pos[lst] - pos[tag]; d -= L * np.round(d / L)
+        r = np.sqrt((d * d).sum(1))
+        assert r.max() < rl + 2e-4
+        exact = nb.get(tag, set())
+        extra = set(lst.tolist()) - exact
+        for j in extra:                              # only shell pairs may be extra
+            dj = pos[j] - pos[tag]; dj -= L * np.round(dj / L)
+            assert np.sqrt((dj * dj).sum()) > rl - 1e-5
+        # pairs of the exact list that are missing carry no potential (inactive type pair): the forces agree
+        checked += 1
+    assert checked > 50
+    assert rel_err(g.get_state("FORCE"), f_ref) < TOL[32]
+
