@@ -1210,21 +1210,33 @@ __device__ __forceinline__ void list_stage_f32(TileLDS<float>& T, unsigned char*
   }
   for (int r = w; r < NROW; r += NW) {
     const int len = T.celloff[r][SX], o0 = T.rowoff[r];
-    for (int e = l; e < len; e += 64) {
-      int k = 0;
+    for (int e0 = 0; e0 < len; e0 += 64) {          // (wave-uniform trip count: the type masks are built with ballots)
+      const int e = e0 + l;
+      int tj = -1;
+      if (e < len) {
+        int k = 0;
 #pragma unroll
-      for (int q = 1; q < SX; ++q) k += (e >= T.celloff[r][q]) ? 1 : 0;
-      const int g = T.cellg[r][k] + (e - T.celloff[r][k]);
-      const int dst = o0 + e;
-      if (dst < CAP) {
-        const float4 p = x4[g];
-        CHEM_LDS float* grp = img + (dst >> 2) * 16 + (dst & 3);
-        const float u = (p.x + T.cellshx[r][k]) - T.org[0], v = (p.y + T.rowshy[r]) - T.org[1], w_ = (p.z + T.rowshz[r]) - T.org[2];
-        grp[0] = u; grp[4] = v; grp[8] = w_; grp[12] = fmaf(u, u, fmaf(v, v, w_ * w_));   // (explicit: the same rounding in every kernel this is inlined into)
-        const int tj = (int)p.w & 15;
-        const unsigned int bit = 0x80000000u >> (dst & 31);
-        for (int ti = 0; ti < ntypes; ++ti)
-          if ((act.row[ti] >> tj) & 1u) __hip_atomic_fetch_or(&tm[ti * L.nwords + (dst >> 5)], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int q = 1; q < SX; ++q) k += (e >= T.celloff[r][q]) ? 1 : 0;
+        const int g = T.cellg[r][k] + (e - T.celloff[r][k]);
+        const int dst = o0 + e;
+        if (dst < CAP) {
+          const float4 p = x4[g];
+          CHEM_LDS float* grp = img + (dst >> 2) * 16 + (dst & 3);
+          const float u = (p.x + T.cellshx[r][k]) - T.org[0], v = (p.y + T.rowshy[r]) - T.org[1], w_ = (p.z + T.rowshz[r]) - T.org[2];
+          grp[0] = u; grp[4] = v; grp[8] = w_; grp[12] = fmaf(u, u, fmaf(v, v, w_ * w_));   // (explicit: the same rounding in every kernel this is inlined into)
+          tj = (int)p.w & 15;
+        }
+      }
+      // 64 consecutive slots = 2 or 3 mask words: one ballot per home type, the three words assembled by shifts and
+      // bit reversal, one atomic each (a per-slot atomic OR is a 32-way same-address conflict in the LDS)
+      const int slot0 = o0 + e0, sh = slot0 & 31, wbase = slot0 >> 5;
+      for (int ti = 0; ti < ntypes; ++ti) {
+        const unsigned long long m = __ballot(tj >= 0 && ((act.row[ti] >> tj) & 1u));
+        if (m == 0ull) continue;
+        const unsigned long long lo = m << sh;
+        const unsigned int w2 = sh ? (unsigned int)(m >> (64 - sh)) : 0u;
+        const unsigned int part = l == 0 ? (unsigned int)lo : (l == 1 ? (unsigned int)(lo >> 32) : w2);
+        if (l < 3 && part) __hip_atomic_fetch_or(&tm[ti * L.nwords + wbase + l], __brev(part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
