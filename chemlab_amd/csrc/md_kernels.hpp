@@ -1148,7 +1148,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
 
 // List build, fp32: LDS layout of one staged tile (inside the same dynamic LDS block the force kernel uses for its
 // float4 image -- 12 + ntypes/8 bytes per slot instead of 16):
-//   img   groups of FOUR slots in SoA order, 64 bytes per group: u0..u3 | v0..v3 | w0..w3 | q0..q3 with (u,v,w) the
+//   img   groups of FOUR slots in SoA order, 64 bytes (+16 of padding, kGrpF) per group: u0..u3 | v0..v3 | w0..w3 | q0..q3 with (u,v,w) the
 //         position relative to the lower corner of the tile's stencil (|u| <= 5 cell edges) and q = u^2+v^2+w^2.  The
 //         test of a candidate is  rl^2 + delta - |ri|^2 - q + 2 ri.(u,v,w) >= 0 : one packed add and three packed FMAs per
 //         TWO candidates instead of 3 sub + 1 mul + 2 fma + 1 sub each -- the loop is bound by VALU issue.  The
@@ -1167,18 +1167,22 @@ constexpr int NBND = SX * NSUB + 1;
 #ifndef CHEM_LIST_DELTA
 #define CHEM_LIST_DELTA 2.5e-4f
 #endif
-constexpr float kListDelta = CHEM_LIST_DELTA;   // see the layout note below: what the expanded distance form may lose on r^2
+constexpr float kListDelta = CHEM_LIST_DELTA;
+// floats per group of four slots in the list-build image: 16 used + 4 of padding.  With a stride of 16 words the reads
+// of lanes on groups g and g + 4 hit the same banks (SQ_LDS_BANK_CONFLICT was 47 % of the LDS cycles of the rebuild);
+// 20 words put 16 consecutive groups on 16 different bank quads.
+constexpr int kGrpF = 20;   // see the layout note below: what the expanded distance form may lose on r^2
 struct ListLDS { int img_bytes, nwords, tmask_off, bnd_off; };
 __device__ __forceinline__ ListLDS list_lds_layout(int CAP, int ntypes) {
   ListLDS L;
-  L.img_bytes = (((CAP + 3) >> 2) + 3) * 64;          // (+ three groups: the pipelined reads run up to two groups past the last slot)
+  L.img_bytes = (((CAP + 3) >> 2) + 3) * kGrpF * 4;          // (+ three groups: the pipelined reads run up to two groups past the last slot)
   L.nwords = ((CAP + 31) >> 5) + 2;
   L.tmask_off = L.img_bytes;
   L.bnd_off = L.tmask_off + ntypes * L.nwords * 4;
   return L;
 }
 __host__ __device__ constexpr size_t list_lds_bytes(int CAP, int ntypes) {
-  return (size_t)(((CAP + 3) >> 2) + 3) * 64 + (size_t)ntypes * (((CAP + 31) >> 5) + 2) * 4 + (size_t)NROW * NBND * 2 + 16;
+  return (size_t)(((CAP + 3) >> 2) + 3) * kGrpF * 4 + (size_t)ntypes * (((CAP + 31) >> 5) + 2) * 4 + (size_t)NROW * NBND * 2 + 16;
 }
 
 // zeroes the type masks (call before the workgroup barriers of tile_tables) ...
@@ -1221,7 +1225,7 @@ __device__ __forceinline__ void list_stage_f32(TileLDS<float>& T, unsigned char*
         const int dst = o0 + e;
         if (dst < CAP) {
           const float4 p = x4[g];
-          CHEM_LDS float* grp = img + (dst >> 2) * 16 + (dst & 3);
+          CHEM_LDS float* grp = img + (dst >> 2) * kGrpF + (dst & 3);
           const float u = (p.x + T.cellshx[r][k]) - T.org[0], v = (p.y + T.rowshy[r]) - T.org[1], w_ = (p.z + T.rowshz[r]) - T.org[2];
           grp[0] = u; grp[4] = v; grp[8] = w_; grp[12] = fmaf(u, u, fmaf(v, v, w_ * w_));   // (explicit: the same rounding in every kernel this is inlined into)
           tj = (int)p.w & 15;
@@ -1435,7 +1439,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
     int lx = 0;
     for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
     const int sself = T.rowoff[hr] + eh;
-    const CHEM_LDS float* self = img + (sself >> 2) * 16 + (sself & 3);
+    const CHEM_LDS float* self = img + (sself >> 2) * kGrpF + (sself & 3);
     const float xix = self[0], xiy = self[4], xiz = self[8];             // relative to the stencil's lower corner
     const float cq = rl2 + kListDelta - self[12];
     const f32x2 ax = {2.f * xix, 2.f * xix}, ay = {2.f * xiy, 2.f * xiy}, az = {2.f * xiz, 2.f * xiz}, cc = {cq, cq};
@@ -1479,7 +1483,8 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
     }
     const bool plain = (e1 == e0 || fastx) && !row32;
     uint4* regq = reinterpret_cast<uint4*>(reg16) + q;   // chunk c of this particle: regq[c * nhome]
-    // accepted slots are shifted into a 128-bit register; every 8th append stores one whole 16-byte chunk
+    // accepted slots are shifted into a 128-bit register; every 8th append stores one whole 16-byte chunk (one
+    // predicated 2-byte store per hit instead was measured slower: tile phase 269 -> 284 us)
     uint4 acc = make_uint4(0, 0, 0, 0);
     auto push = [&](unsigned int sl) {
       acc.x = __builtin_amdgcn_alignbit(acc.y, acc.x, 16);
@@ -1526,7 +1531,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
       for (int s0 = a & ~3; s0 < b; s0 += 32) {
         const int len = (b - s0) < 32 ? (b - s0) : 32;
         const int ng = (len + 3) >> 2;
-        lds_f32x4* gp = (lds_f32x4*)(l3) + 4 * (s0 >> 2);
+        lds_f32x4* gp = (lds_f32x4*)(l3) + (kGrpF / 4) * (s0 >> 2);
         const unsigned int w0 = tmrow[s0 >> 5], w1 = tmrow[(s0 >> 5) + 1];
         // two groups per trip, ping-pong registers: the reads of the group after next are in flight while one is tested
         f32x4 X0 = gp[0], Y0 = gp[1], Z0 = gp[2], Q0 = gp[3];
@@ -1543,9 +1548,9 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
         };
         const int ng2 = (ng + 1) & ~1;                                // (the odd group's bits fall behind `len` and are masked)
         for (int g = 0; g < ng2; g += 2) {
-          const f32x4 X1 = gp[4], Y1 = gp[5], Z1 = gp[6], Q1 = gp[7];
+          const f32x4 X1 = gp[kGrpF / 4], Y1 = gp[kGrpF / 4 + 1], Z1 = gp[kGrpF / 4 + 2], Q1 = gp[kGrpF / 4 + 3];
           test4(X0, Y0, Z0, Q0);
-          gp += 8;
+          gp += 2 * (kGrpF / 4);
           X0 = gp[0]; Y0 = gp[1]; Z0 = gp[2]; Q0 = gp[3];             // (up to two groups past the run: allocated, never used)
           test4(X1, Y1, Z1, Q1);
         }
@@ -1584,7 +1589,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
 #pragma unroll
             for (int qq = 1; qq < SX; ++qq) kc += (e >= T.celloff[r][qq]) ? 1 : 0;
             const int j = T.cellg[r][kc] + (e - T.celloff[r][kc]);
-            const CHEM_LDS float* cj = img + (sl >> 2) * 16 + (sl & 3);
+            const CHEM_LDS float* cj = img + (sl >> 2) * kGrpF + (sl & 3);
             const float ddx = xix - cj[0], ddy = xiy - cj[4], ddz = xiz - cj[8];
             const bool exact = ddx * ddx + ddy * ddy + ddz * ddz <= rl2;  // difference form: the mask is a superset by the delta shell
             bool ok = true;
