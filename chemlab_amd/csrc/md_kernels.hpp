@@ -2012,12 +2012,12 @@ __device__ __forceinline__ int block_scan_excl(int v, int* total) {
 // entries' partner tags already resolved to particle indices.  The per-step kernel runs over the
 // owners only, with full waves (the fp64 term code is long: a wave with one bonded lane costs as
 // much as a full one), and has two dependent loads in front of the arithmetic instead of five.
+// one chunk of BS particles starting at ib (block-uniform; ends with a workgroup barrier)
 template <int BS>
-__device__ __forceinline__ void dev_bonded_prep(int i0, int n, const int* tag, const int* rtag, const int* bstart, const BondedEntry* bent,
-                                                int4* bwork, int4* bj, DevCtl* ctl) {
+__device__ __forceinline__ void dev_bonded_prep_chunk(int ib, int iend, const int* tag, const int* rtag, const int* bstart, const BondedEntry* bent,
+                                                      int4* bwork, int4* bj, DevCtl* ctl) {
   __shared__ int s_base;
-  const int iend = i0 + n;
-  for (int ib = i0 + blockIdx.x * BS; ib < iend; ib += gridDim.x * BS) {   // block-uniform bound (block scan below)
+  {
     const int i = ib + threadIdx.x;
     int e0 = 0, e1 = 0;
     if (i < iend) { const int tg = tag[i]; e0 = bstart[tg]; e1 = bstart[tg + 1]; }
@@ -2030,6 +2030,12 @@ __device__ __forceinline__ void dev_bonded_prep(int i0, int n, const int* tag, c
     for (int e = e0; e < e1; ++e) { const BondedEntry be = bent[e]; bj[e] = make_int4(rtag[be.t0], rtag[be.t1], rtag[be.t2], 0); }
     __syncthreads();
   }
+}
+template <int BS>
+__device__ __forceinline__ void dev_bonded_prep(int i0, int n, const int* tag, const int* rtag, const int* bstart, const BondedEntry* bent,
+                                                int4* bwork, int4* bj, DevCtl* ctl) {
+  for (int ib = i0 + blockIdx.x * BS; ib < i0 + n; ib += gridDim.x * BS)    // block-uniform bound (block scan inside)
+    dev_bonded_prep_chunk<BS>(ib, i0 + n, tag, rtag, bstart, bent, bwork, bj, ctl);
 }
 
 __global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* __restrict__ tag, const int* __restrict__ rtag, const int* __restrict__ bstart,
@@ -2075,6 +2081,7 @@ struct GridBar {
   unsigned int top[32];        // groups arrived
   unsigned int gen[32];        // generation (release flag)
   unsigned int tq[8][32];      // tile queue heads, one per XCD
+  unsigned int prepq[32];      // head of the bonded-work-list chunk queue
   long long stamp[16];         // wall_clock64 of workgroup 0 at the phase boundaries of the last rebuild (diagnostics)
 };
 
@@ -2200,7 +2207,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
 #define WGST(K) do { if (wst && t == 0) wst[K] = wall_clock64(); } while (0)
   WGST(0);
   if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
-  if (b == 0 && t == 8) ctl->bwork_count = 0;
+  if (b == 0 && t == 8) { ctl->bwork_count = 0; a.gb->prepq[0] = 0u; }
   { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl, a.bucket, a.bcap, a.btot, a.seg_shift); }
   WGST(1);
   if (!grid_barrier(a.gb, ctl)) return; WGST(2); if (b == 0 && t == 0) { const long long st = wall_clock64(); a.gb->stamp[1] = st; a.gb->stamp[2] = st; a.gb->stamp[3] = st; }
@@ -2265,7 +2272,6 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
       }
       __syncthreads();
     }
-    if (a.nbent > 0) dev_bonded_prep<BS>(0, a.n, a.tago, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl);   // rtag is complete since the last barrier
     const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
     int ndone = 0;
     WGST(5);
@@ -2323,6 +2329,19 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
     }
     WGST(6);
     if (wst && t == 0) wst[7] = ndone;
+    // bonded work list (nothing in this launch reads it): chunks of BS particles from a queue, taken by workgroups that
+    // have run out of tiles -- as a fixed share in front of the tiles it was 25 us on every workgroup's critical path,
+    // here it fills the idle tail of the phase (rtag is complete since the last barrier)
+    if (a.nbent > 0) {
+      for (;;) {
+        __syncthreads();
+        if (t == 0) s_tile = (int)atomicAdd(&a.gb->prepq[0], 1u);
+        __syncthreads();
+        const int ib = s_tile * BS;
+        if (ib >= a.n) break;
+        dev_bonded_prep_chunk<BS>(ib, a.n, a.tago, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl);
+      }
+    }
     // copy-back (+ reference positions): every workgroup moves its share once it has no tile left
     for (int k = b * BS + t; k < a.n; k += NB * BS) {
       const Vec4<R> xk = a.x4o[k];

@@ -14,3 +14,4 @@ rocprofv3 --pmc SQ_INST_LEVEL_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT
 rocprofv3 --pmc SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU --kernel-trace --output-format csv -d $OUT/p4 -- python3 $R/bench.py $S > $OUT/p4.json 2> $OUT/p4.err; echo p4
 cd $R
 python3 tools/pmc_kernels.py $(find $OUT/p1 $OUT/p2 $OUT/p3 $OUT/p4 -name "*counter_collection.csv") --match=rebuild_fused,pair_tiles > $OUT/pmc.txt
+rm -rf $OUT/p1 $OUT/p2 $OUT/p3 $OUT/p4

@@ -20,4 +20,6 @@ EQUIL=1500 python3 tools/tile_stamps.py 1000000 > $OUT/tile_stamps.txt 2>&1 || t
 python3 tools/kstats.py $(find $OUT/stats -name "*kernel_stats.csv" | head -1) 24 > $OUT/kernel_stats.txt
 python3 tools/pmc_kernels.py $(find $OUT/pmcA $OUT/pmcB -name "*counter_collection.csv") > $OUT/pmc_sq.txt
 python3 tools/pmc_traffic_kernels.py $(find $OUT/pmcF -name "*counter_collection.csv" | head -1) $(find $OUT/pmcW -name "*counter_collection.csv" | head -1) 1000000 > $OUT/kernel_traffic.json
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+rm -rf $OUT/pmcA $OUT/pmcB $OUT/pmcF $OUT/pmcW $OUT/stats     # raw traces: tens of MB per pass (gpurun merges back at most 64 MiB)
 echo "summaries done"

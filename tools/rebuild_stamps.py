@@ -11,6 +11,9 @@ W.apply(spec, e)
 for kv in sys.argv[2:]:
     k, v = kv.split('='); e.set_option(k, float(v))
 e.reactions_enable(False); e.run(int(os.environ.get("EQUIL", "50")))
+rs = int(os.environ.get("REACT_STEPS", "0"))
+if rs:
+    e.reactions_enable(True); e.run(rs)      # bonds, exclusions and bonded work lists in the rebuild
 e.set_option("debug_stamps", 1)
 e.run(12)
 e.sync()
