@@ -223,7 +223,7 @@ template <typename R> struct CtxT : Ctx {
   ActMask act{}; UniLJ uni{}; bool uniform_lj = false; bool all_active = false;
   int ntiles = 0;
   DBuf<int> excl_start, excl_list; int has_excl = 0;
-  DBuf<int> bstart; DBuf<BondedEntry> bent; DBuf<BondedParam> bpar; int64_t nbent = 0;
+  DBuf<int> bstart; DBuf<BondedEntry> bent; DBuf<BondedParam> bpar; int64_t nbent = 0; bool bonds_only = false;
   DBuf<PairCore<R>> pcore; DBuf<PairExt<R>> pext;
   DBuf<DevCtl> ctl;
   DBuf<unsigned long long> blockmax;
@@ -570,6 +570,9 @@ template <typename R> struct CtxT : Ctx {
     top.build_params(hp, hk);
     static_assert(sizeof(HBondedParam) == sizeof(BondedParam) && sizeof(HostTopology::HSlotKey) == sizeof(SlotKey), "layout");
     nslot = (int)hp.size();
+    // analytic pair terms only (the chain-growth systems): the per-step kernel without the angle / dihedral / table code
+    bonds_only = nslot > 0;
+    for (const auto& q : hp) bonds_only &= q.arity == 2 && (q.kind == CHEM_POT_HARMONIC || q.kind == CHEM_POT_FENE || q.kind == CHEM_POT_FENE_LJ || q.kind == CHEM_POT_LJ_BOND);
     bpar.alloc(std::max<size_t>(hp.size(), 1)); skeys.alloc(std::max<size_t>(hk.size(), 1));
     if (nslot) {
       HIPCHK(hipMemcpyAsync(bpar.p, hp.data(), hp.size() * sizeof(BondedParam), hipMemcpyHostToDevice, stream));
@@ -967,12 +970,13 @@ template <typename R> struct CtxT : Ctx {
     if (nbent > 0 && (use_fused || dd_on)) {
       // work-list kernel: owners only, partner indices resolved at the last rebuild
       if (bwork_dirty) {   // bonded lists changed without a rebuild since
-        HIPCHK(hipMemsetAsync(&ctl.p->bwork_count, 0, sizeof(int), stream));
+        HIPCHK(hipMemsetAsync(&ctl.p->bw64, 0, sizeof(unsigned long long), stream));
         hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
         bwork_dirty = false;
       }
       if (timed) tbeg(3);
-      hipLaunchKernelGGL((k_bonded_work<R>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
+      if (bonds_only) hipLaunchKernelGGL((k_bonded_work<R, true>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
+      else hipLaunchKernelGGL((k_bonded_work<R, false>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
       if (timed) tend();
     } else if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,

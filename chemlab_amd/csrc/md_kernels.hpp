@@ -59,10 +59,9 @@ struct DevCtl {
   int barrier_timeout;                // fused rebuild: a grid barrier gave up waiting (fatal)
   int pad0;
   double acc_pp[2];                   // fused rebuild: accumulated distance, double-buffered by launch parity
-  int bwork_count;                    // particles in the bonded work list
+  unsigned long long bw64;            // bonded work list: owners (low word) and entries (high word), one atomic per chunk
   int excl_slot_error;                // list build: an excluded partner was not found in the cell computed from its position (internal)
   int bucket_overflow;                // fused rebuild: a cell holds more particles than a bucket row (value = needed capacity)
-  int pad1;
 };
 
 template <typename R> struct Box {
@@ -1850,12 +1849,14 @@ template <typename R> __device__ __forceinline__ D3 posD(const Vec4<R>& v) { ret
 struct BTab { const double2* rows; const double4* info; };
 
 // one bonded term seen from member `me` of the tuple (j0..j3 = particle indices of the tuple in order)
-template <typename R, bool ENERGY>
+// BONDS_ONLY: the caller guarantees arity 2 and an analytic kind (harmonic, FENE, FENE+LJ, LJ pair) -- the angle, dihedral
+// and table code is not compiled in, which is what brings the per-step kernel from 209 to a few dozen registers
+template <typename R, bool ENERGY, bool BONDS_ONLY = false>
 __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me, const int j0, const int j1, const int j2, const int j3,
                                             const Vec4<R>* __restrict__ x4, const BoxD& box, D3& f, double* __restrict__ elist, DevCtl* ctl, const BTab& bt) {
     const double* p = bp.p;
     double u = 0;
-    if (bp.arity == 2) {
+    if (BONDS_ONLY || bp.arity == 2) {
       // tuple (t0,t1); r_ij = x_t0 - x_t1
       if ((j0 | j1) < 0) { ctl->bonded_missing = 1; return; }
       const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]);
@@ -1877,7 +1878,7 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
           ff = 24.0 * p[0] * (2.0 * s6 * s6 - s6) / (r * r);
         }
       }
-      else if (bp.kind == CHEM_POT_TABULATED) {   // Tabulated(itype=1): linear interpolation of e(r), f(r); end rows beyond the grid
+      else if (!BONDS_ONLY && bp.kind == CHEM_POT_TABULATED) {   // Tabulated(itype=1): linear interpolation of e(r), f(r); end rows beyond the grid
         const double4 ti = bt.info[(int)p[0]];
         const double2* row = bt.rows + (size_t)ti.x;
         const int nrow = (int)ti.y;
@@ -1890,6 +1891,7 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
       }
       const double sgn = me == 0 ? 1.0 : -1.0;
       f = f + (sgn * ff) * d;
+    } else if (BONDS_ONLY) {
     } else if (bp.arity == 3) {
       if ((j0 | j1 | j2) < 0) { ctl->bonded_missing = 1; return; }
       const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]), x2 = posD<R>(x4[j2]);
@@ -2016,18 +2018,26 @@ __device__ __forceinline__ int block_scan_excl(int v, int* total) {
 template <int BS>
 __device__ __forceinline__ void dev_bonded_prep_chunk(int ib, int iend, const int* tag, const int* rtag, const int* bstart, const BondedEntry* bent,
                                                       int4* bwork, int4* bj, DevCtl* ctl) {
-  __shared__ int s_base;
+  __shared__ int s_base, s_ebase;
   {
     const int i = ib + threadIdx.x;
     int e0 = 0, e1 = 0;
     if (i < iend) { const int tg = tag[i]; e0 = bstart[tg]; e1 = bstart[tg + 1]; }
     const int has = e1 > e0 ? 1 : 0;
-    int tot;
+    int tot, etot;
     const int rank = block_scan_excl<BS>(has, &tot);       // one global atomic per block and pass, not per wave:
-    if (threadIdx.x == 0) s_base = tot ? atomicAdd(&ctl->bwork_count, tot) : 0;   // same-address atomics cost ~12 ns each
+    const int erank = block_scan_excl<BS>(e1 - e0, &etot); // (same-address atomics cost ~12 ns each)
+    if (threadIdx.x == 0) {
+      const unsigned long long old = tot ? atomicAdd(&ctl->bw64, ((unsigned long long)etot << 32) | (unsigned long long)tot) : 0ull;
+      s_base = (int)(old & 0xffffffffull); s_ebase = (int)(old >> 32);
+    }
     __syncthreads();
-    if (has) bwork[s_base + rank] = make_int4(i, e0, e1, 0);
-    for (int e = e0; e < e1; ++e) { const BondedEntry be = bent[e]; bj[e] = make_int4(rtag[be.t0], rtag[be.t1], rtag[be.t2], 0); }
+    // the entries of an owner follow each other IN WORK-LIST ORDER (the per-tag CSR is in tag order, i.e. scattered for
+    // neighbouring particles): the per-step kernel reads one coalesced 16-byte record per entry -- partner indices and
+    // the parameter slot / own position -- and nothing else
+    const int eo = s_ebase + erank;
+    if (has) bwork[s_base + rank] = make_int4(i, eo, e1 - e0, 0);
+    for (int e = e0; e < e1; ++e) { const BondedEntry be = bent[e]; bj[eo + (e - e0)] = make_int4(rtag[be.t0], rtag[be.t1], rtag[be.t2], be.meta); }
     __syncthreads();
   }
 }
@@ -2043,21 +2053,21 @@ __global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* _
   dev_bonded_prep<256>(i0, n, tag, rtag, bstart, bent, bwork, bj, ctl);
 }
 
-template <typename R>
+template <typename R, bool BONDS_ONLY = false>
 __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int4* __restrict__ bwork, const int4* __restrict__ bj,
                                                      const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl, int guard, BTab bt) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= ctl->bwork_count || (guard && ctl->need_rebuild)) return;
+  if (k >= (int)(ctl->bw64 & 0xffffffffull) || (guard && ctl->need_rebuild)) return;
   const int4 wk = bwork[k];
   D3 f = {0, 0, 0};
-  for (int e = wk.y; e < wk.z; ++e) {
-    const int meta = bent[e].meta;
+  for (int e = wk.y; e < wk.y + wk.z; ++e) {
     const int4 jj = bj[e];
+    const int meta = jj.w;
     const int slot = meta & 0x0fffffff, me = (meta >> 28) & 3;
     const BondedParam& bp = bpar[slot];
     int j3 = 0;
-    if (bp.arity == 4) { j3 = bj[e + 1].x; ++e; }
-    bonded_term<R, false>(bp, me, jj.x, jj.y, bp.arity > 2 ? jj.z : 0, j3, x4, box, f, nullptr, ctl, bt);
+    if (!BONDS_ONLY && bp.arity == 4) { j3 = bj[e + 1].x; ++e; }
+    bonded_term<R, false, BONDS_ONLY>(bp, me, jj.x, jj.y, (!BONDS_ONLY && bp.arity > 2) ? jj.z : 0, j3, x4, box, f, nullptr, ctl, bt);
   }
   Vec4<R> fo = f4[wk.x];
   fo.x += (R)f.x; fo.y += (R)f.y; fo.z += (R)f.z;
@@ -2207,7 +2217,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
 #define WGST(K) do { if (wst && t == 0) wst[K] = wall_clock64(); } while (0)
   WGST(0);
   if (b == 0 && t < 8) a.gb->tq[t][0] = 0u;
-  if (b == 0 && t == 8) { ctl->bwork_count = 0; a.gb->prepq[0] = 0u; }
+  if (b == 0 && t == 8) { ctl->bw64 = 0ull; a.gb->prepq[0] = 0u; }
   { MigBuf<R> none{}; dev_bin<R>(0, a.n, a.x4, a.v4, a.tag, a.img4, a.box, a.cell_cnt, a.cell_of, a.slot_of, none, none, ctl, a.bucket, a.bcap, a.btot, a.seg_shift); }
   WGST(1);
   if (!grid_barrier(a.gb, ctl)) return; WGST(2); if (b == 0 && t == 0) { const long long st = wall_clock64(); a.gb->stamp[1] = st; a.gb->stamp[2] = st; a.gb->stamp[3] = st; }
