@@ -131,6 +131,7 @@ struct Ctx {
   int opt_time_pair = 0;    // HIP-event timing of every N-th pair-force launch (0 = off)
   int64_t pair_launch_no = 0;
   int opt_fuse = 1;         // fused integrate2+integrate1
+  int opt_dd_merge = 1;     // decomposed path: displacement fold in the integrate kernel, decision in the force kernel (no one-block launches)
   int opt_ablate_list = 0;  // diagnostics (with debug_stamps): parts of the list build left out, see tools/rebuild_stamps.py
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
   int opt_fused = 1;        // rebuild chain as one persistent launch with grid barriers (single domain, tiles)
@@ -227,6 +228,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<PairCore<R>> pcore; DBuf<PairExt<R>> pext;
   DBuf<DevCtl> ctl;
   DBuf<unsigned long long> blockmax;
+  DBuf<unsigned int> foldc; int dd_par = 0; DecideArgs pair_da{};   // decomposed path: arrival counters of the fold, parity of the accumulated distance, decision arguments of the force launch
   DBuf<double> eout, ekout, elist;
   // reactions
   DBuf<Candidate> cand, evout; int cand_cap = 0;
@@ -863,7 +865,7 @@ template <typename R> struct CtxT : Ctx {
   void rebuild_now() {
     const double t0 = now_s();
     for (int attempt = 0; attempt < 6; ++attempt) {
-      if (dd_on) { set_ctl_field(&DevCtl::force_rebuild, 0); set_ctl_field(&DevCtl::acc_maxdist, 0.0); rebuild_dd(); }
+      if (dd_on) { set_ctl_field(&DevCtl::force_rebuild, 0); set_ctl_field(&DevCtl::acc_maxdist, 0.0); HIPCHK(hipMemsetAsync(ctl.p->acc_pp, 0, 2 * sizeof(double), stream)); rebuild_dd(); }
       else { set_ctl_field(&DevCtl::force_rebuild, 1); decide_and_rebuild(); }
       DevCtl h = read_ctl();
       if (dd_on) agree_flags(h);
@@ -932,7 +934,7 @@ template <typename R> struct CtxT : Ctx {
       else if (pair_subset == 2) { ts = TileSub{0, ntxy, ntiles - ntxy}; nsub = 2 * ntxy; }
       if (nsub <= 0) return 0;
 #define LTD(T, M, B, D) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M, D>), dim3(nsub), dim3(B), tile_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
-                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, pair_guard, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr, ts)
+                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, pair_guard, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr, ts, pair_da)
 #define LT(T, M, B) LTD(T, M, B, false)
       // diagnostics (options debug_stamps / ablate): one instantiation, one lane per particle, 512 threads
 #define LTB(T, M) do { if ((dbg_on || opt_ablate) && !ENERGY) { if (T != 1 || pair_bs != 512) throw ChemError(CHEM_EINVAL, "debug_stamps / ablate need tpp=1 and pair_block=512"); LTD(1, M, 512, true); } \
@@ -958,7 +960,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   void compute_forces(bool speculative = false, int subset = 0) {
-    pair_guard = speculative ? 1 : 0;
+    pair_guard = speculative ? (pair_da.gathered ? 2 : 1) : 0;
     pair_subset = subset;
     const int tpp = pick_tpp();
     const bool timed = timed_step && subset == 0;
@@ -996,12 +998,15 @@ template <typename R> struct CtxT : Ctx {
     // CapForce acts on the freshly evaluated conservative force: every launch that applies the thermostat
     // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
     const R cap = (cap_force > 0 && (with_lang || !lang)) ? (R)cap_force : (R)0;
+    // (the last-block fold of the maxima inside this kernel -- foldc -- is not used: every block needs a device-scope
+    //  release fence before it signals its arrival, which made this 18 us kernel take 82 us)
+    unsigned int* fc = nullptr;
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, fc, ctl.p);
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, fc, ctl.p);
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, fc, ctl.p);
   }
 
   void check_flags() {
@@ -1027,8 +1032,30 @@ template <typename R> struct CtxT : Ctx {
   // one step's neighbour bookkeeping in slab mode: cross-rank max of the displacement, the ghost
   // position update (posted before the decision is known: it is needed unless we rebuild), and the
   // collective rebuild when the trigger fired.  One host synchronisation per step.
+  bool dd_overlap() const {
+    const int ntxy = ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY);
+    const bool want_overlap = opt_overlap > 0 || (opt_overlap < 0 && ntiles >= 8192);
+    return want_overlap && use_tiles && ntiles > 2 * ntxy && !getenv("CHEM_DD_NOPOLL");
+  }
+  // decision by the force kernel's workgroups instead of a one-block launch between the halo exchange and the forces
+  bool dd_merged() const { return dd_on && opt_dd_merge && use_tiles && !dd_overlap() && !getenv("CHEM_DD_NOPOLL"); }
   void dd_step_sync() {
     ensure_hflag();
+    if (dd_merged()) {
+      hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), kIntPerBlock), 0.5 * skin, opt_criterion, 1,
+                         (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+      tr->exchange_with_scalar(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
+                               x4.p + G - nglo, nglo * sizeof(V4), lower, upper, &ctl.p->step_m2, dd_vals.p, stream);
+      const int ticket = ++hticket;
+      pair_da = DecideArgs{dd_vals.p, P, (volatile int*)hflag_dev, ticket, dd_par, opt_criterion};
+      dd_par ^= 1;
+      compute_forces(true, 0);     // (guard 2: decision in the prologue of the force kernel)
+      pair_da = DecideArgs{};
+      volatile int* hf = hflag;
+      poll_ticket(hflag + 1, ticket, "rebuild decision");
+      if (hf[0]) { rebuild_dd(); compute_forces(); }
+      return;
+    }
     // local fold -> ctl->step_m2; its all-to-all rides in the halo exchange group; decision from the
     // P gathered values, mirrored into pinned host memory so that the host learns it by polling one
     // word (no memcpy, no stream synchronisation call)
@@ -2069,6 +2096,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "time_pair_kernel") CTX.opt_time_pair = value > 0 ? (int)value : 0;
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
   else if (k == "ablate_list") CTX.opt_ablate_list = (int)value;
+  else if (k == "dd_merge") CTX.opt_dd_merge = value != 0;
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else if (k == "fused_rebuild") { CTX.opt_fused = value != 0; CTX.geom_dirty = true; }
   else if (k == "overlap_halo") CTX.opt_overlap = value < 0 ? -1 : (value != 0 ? 1 : 0);

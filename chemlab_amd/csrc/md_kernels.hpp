@@ -123,7 +123,7 @@ template <typename R, int MODE, bool LANG, bool STOREF>
 __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
                                                     R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax,
-                                                    const Vec4<R>* __restrict__ x0, R cap) {
+                                                    const Vec4<R>* __restrict__ x0, R cap, unsigned int* __restrict__ foldc = nullptr, DevCtl* fctl = nullptr) {
   // kIntPerBlock particles per 256-thread block: every thread owns kIntPerBlock/256 particles and issues
   // all their loads before the first dependent instruction (more bytes in flight per wave for this
   // purely HBM-bound kernel); the arithmetic per particle is unchanged
@@ -179,6 +179,39 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
       unsigned long long m = wm[0];
       for (int k = 1; k < 4; ++k) m = wm[k] > m ? wm[k] : m;
       blockmax[blockIdx.x] = m;
+    }
+    // Decomposed path: the block that finishes last folds the per-block maxima into ctl->step_m2 -- what the halo
+    // exchange group carries to the other ranks -- instead of a one-block launch of its own between this kernel and
+    // the exchange.  Arrival counters in two levels (64 groups, 128-byte spacing): same-address atomics take ~12 ns each.
+    if (foldc) {
+      __shared__ int s_last;
+      if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int g = blockIdx.x & 63u, ngrp = gridDim.x < 64u ? gridDim.x : 64u, gsize = (gridDim.x - g + 63u) >> 6;
+        int last = 0;
+        if (atomicAdd(&foldc[g * 32], 1u) == gsize - 1u) {
+          __hip_atomic_store(&foldc[g * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (atomicAdd(&foldc[64 * 32], 1u) == ngrp - 1u) { __hip_atomic_store(&foldc[64 * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
+        }
+        s_last = last;
+      }
+      __syncthreads();
+      if (s_last) {
+        __threadfence();
+        unsigned long long m = 0;
+        for (unsigned int k = threadIdx.x; k < gridDim.x; k += 256) {
+          const unsigned long long v = __hip_atomic_load(&blockmax[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          m = v > m ? v : m;
+        }
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(m, o); m = v > m ? v : m; }
+        __syncthreads();
+        if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          for (int k = 0; k < 4; ++k) m = wm[k] > m ? wm[k] : m;
+          fctl->step_m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
+        }
+      }
     }
   }
 }
@@ -1619,7 +1652,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
 }
 
 template <typename R, int BS>
-__global__ __launch_bounds__(BS, 6) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+__global__ __launch_bounds__(BS, 4) void k_nlist_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
                                                     const TileLDS<R>* __restrict__ desc, R rl2,
                                                     const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
                                                     ActMask act, int ntypes, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
@@ -1707,6 +1740,11 @@ struct UniLJ { float rc2, lj1, lj2, pad; double drc2, dlj1, dlj2; };   // all li
 // tiles whose stencil stays inside the own layers ("interior": they need no ghost) while the halo
 // exchange is still in flight on the communication stream, and the two boundary tile layers after it.
 struct TileSub { int base1, n1, base2; };
+// guard == 2 (decomposed path): every workgroup of the force kernel takes the rebuild decision itself from the P
+// gathered step maxima (same inputs, same arithmetic: same result), workgroup 0 publishes it -- control block, pinned
+// host words the host polls -- and all leave at once when a rebuild is due: no one-block decision launch between the
+// halo exchange and the forces.  The accumulated distance is double-buffered by step parity (read [par], written [par^1]).
+struct DecideArgs { const double* gathered; int n; volatile int* host_flag; int ticket, par, criterion; };
 
 // DIAG = true: diagnostic instantiation with per-block phase stamps (`dbg`) and early exits (`ablate`: 1 stop after
 // staging, 2 skip staging, 3 descriptor only, 4 dispatch only); the production instantiation carries neither.
@@ -1717,18 +1755,33 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
                                                    const int* __restrict__ nnh, int S16,
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
                                                    int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
-                                                   double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_) {
+                                                   double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_,
+                                                   DecideArgs da = DecideArgs{}) {
   constexpr bool LJONLY = MODE >= 1;
   constexpr int NCH = TPP == 1 ? 3 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
   if (DIAG && dbg) st0 = wall_clock64();
   if (DIAG && ablate == 4) return;   // diagnostic: dispatch cost only
-  if (guard && ctl->need_rebuild) return;   // speculative launch (decomposed path): the host rebuilds first and launches again
+  if (guard == 2) {
+    double m2 = da.gathered[0];
+    for (int q = 1; q < da.n; ++q) m2 = da.gathered[q] > m2 ? da.gathered[q] : m2;
+    const double acc = da.criterion ? sqrt(m2) : ctl->acc_pp[da.par] + sqrt(m2);
+    const int need = (acc > half_skin) || ctl->force_rebuild;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      ctl->step_m2 = m2; ctl->acc_pp[da.par ^ 1] = need ? 0.0 : acc; ctl->acc_maxdist = need ? 0.0 : acc;
+      if (need) { ctl->force_rebuild = 0; ctl->rebuild_count++; }
+      ctl->need_rebuild = need;
+      da.host_flag[0] = need;
+      __threadfence_system();
+      da.host_flag[1] = da.ticket;
+    }
+    if (need) return;
+  } else if (guard && ctl->need_rebuild) return;   // speculative launch (decomposed path): the host rebuilds first and launches again
   __shared__ TileLDS<R> T;
   __shared__ PairCore<R> spc[kMaxTypes * kMaxTypes];
   CHEM_DYN_LDS(R);
   if (MODE != 2) for (int k = threadIdx.x; k < ntypes * ntypes; k += BS) spc[k] = pcore[k];
-  if (blockIdx.x == 0 && threadIdx.x == 0 && ctl->acc_maxdist > half_skin) ctl->skin_violation = 1;
+  if (guard != 2 && blockIdx.x == 0 && threadIdx.x == 0 && ctl->acc_maxdist > half_skin) ctl->skin_violation = 1;
   const R u_rc2 = sizeof(R) == 4 ? (R)uni.rc2 : (R)uni.drc2, u_lj1 = sizeof(R) == 4 ? (R)uni.lj1 : (R)uni.dlj1,
           u_lj2 = sizeof(R) == 4 ? (R)uni.lj2 : (R)uni.dlj2;
   const int vtile = xcd_remap(blockIdx.x, ntiles);   // ntiles = tiles of THIS launch (all of them, or one of the two subsets below)
