@@ -228,7 +228,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<PairCore<R>> pcore; DBuf<PairExt<R>> pext;
   DBuf<DevCtl> ctl;
   DBuf<unsigned long long> blockmax;
-  DBuf<unsigned int> foldc; int dd_par = 0; DecideArgs pair_da{};   // decomposed path: arrival counters of the fold, parity of the accumulated distance, decision arguments of the force launch
+  int dd_par = 0; DecideArgs pair_da{};   // decomposed path: parity of the accumulated distance, decision arguments of the force launch
   DBuf<double> eout, ekout, elist;
   // reactions
   DBuf<Candidate> cand, evout; int cand_cap = 0;
@@ -998,15 +998,12 @@ template <typename R> struct CtxT : Ctx {
     // CapForce acts on the freshly evaluated conservative force: every launch that applies the thermostat
     // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
     const R cap = (cap_force > 0 && (with_lang || !lang)) ? (R)cap_force : (R)0;
-    // (the last-block fold of the maxima inside this kernel -- foldc -- is not used: every block needs a device-scope
-    //  release fence before it signals its arrival, which made this 18 us kernel take 82 us)
-    unsigned int* fc = nullptr;
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, fc, ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, fc, ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, fc, ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
   }
 
   void check_flags() {

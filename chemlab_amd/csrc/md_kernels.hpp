@@ -123,7 +123,7 @@ template <typename R, int MODE, bool LANG, bool STOREF>
 __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
                                                     R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax,
-                                                    const Vec4<R>* __restrict__ x0, R cap, unsigned int* __restrict__ foldc = nullptr, DevCtl* fctl = nullptr) {
+                                                    const Vec4<R>* __restrict__ x0, R cap) {
   // kIntPerBlock particles per 256-thread block: every thread owns kIntPerBlock/256 particles and issues
   // all their loads before the first dependent instruction (more bytes in flight per wave for this
   // purely HBM-bound kernel); the arithmetic per particle is unchanged
@@ -179,39 +179,6 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
       unsigned long long m = wm[0];
       for (int k = 1; k < 4; ++k) m = wm[k] > m ? wm[k] : m;
       blockmax[blockIdx.x] = m;
-    }
-    // Decomposed path: the block that finishes last folds the per-block maxima into ctl->step_m2 -- what the halo
-    // exchange group carries to the other ranks -- instead of a one-block launch of its own between this kernel and
-    // the exchange.  Arrival counters in two levels (64 groups, 128-byte spacing): same-address atomics take ~12 ns each.
-    if (foldc) {
-      __shared__ int s_last;
-      if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned int g = blockIdx.x & 63u, ngrp = gridDim.x < 64u ? gridDim.x : 64u, gsize = (gridDim.x - g + 63u) >> 6;
-        int last = 0;
-        if (atomicAdd(&foldc[g * 32], 1u) == gsize - 1u) {
-          __hip_atomic_store(&foldc[g * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (atomicAdd(&foldc[64 * 32], 1u) == ngrp - 1u) { __hip_atomic_store(&foldc[64 * 32], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); last = 1; }
-        }
-        s_last = last;
-      }
-      __syncthreads();
-      if (s_last) {
-        __threadfence();
-        unsigned long long m = 0;
-        for (unsigned int k = threadIdx.x; k < gridDim.x; k += 256) {
-          const unsigned long long v = __hip_atomic_load(&blockmax[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          m = v > m ? v : m;
-        }
-        for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(m, o); m = v > m ? v : m; }
-        __syncthreads();
-        if (lane_id() == 0) wm[threadIdx.x >> 6] = m;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-          for (int k = 0; k < 4; ++k) m = wm[k] > m ? wm[k] : m;
-          fctl->step_m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
-        }
-      }
     }
   }
 }
