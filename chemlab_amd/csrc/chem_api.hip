@@ -919,7 +919,7 @@ template <typename R> struct CtxT : Ctx {
   // ---- forces -------------------------------------------------------------------------
   int pick_tpp() const {
     if (opt_tpp > 0) return use_tiles ? std::min(opt_tpp, 8) : opt_tpp;
-    if (use_tiles) return ntiles >= 768 ? 1 : 2;   // one lane per home particle once the tiles alone fill the chip (3 workgroups x 256 CUs)
+    if (use_tiles) return 1;   // one lane per home particle at every size (measured 10k..1M particles after the ds_read_b128 fix: 125k particles 17.4 us against 20.6 with two lanes)
     return n >= 100000 ? 4 : (n >= 8000 ? 8 : 16);
   }
 
