@@ -358,7 +358,7 @@ template <typename R> struct CtxT : Ctx {
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
     a.wgst = dbg_on && wgst.p ? wgst.p : nullptr;
     a.bstart = bstart.p; a.bent = bent.p; a.bwork = bwork.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
-    if (dbg_on) hipLaunchKernelGGL((k_rebuild_fused<R, 512, true>), dim3(fused_grid), dim3(512), list_lds_need(), stream, a);
+    if (dbg_on || want32) hipLaunchKernelGGL((k_rebuild_fused<R, 512, true>), dim3(fused_grid), dim3(512), list_lds_need(), stream, a);
     else hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), list_lds_need(), stream, a);
     fused_par ^= 1;
   }

@@ -2204,7 +2204,7 @@ __device__ __forceinline__ void seg_scan(int* cnt, int nitem, int shift, int* lo
 #define CHEM_FUSED_WAVES 4
 #endif
 // DIAG = true: diagnostic instantiation (option debug_stamps) with the per-workgroup phase stamps and the ablation switch of
-// the list build; the production instantiation carries neither (their uniform branches in the peel loop cost 7 % of the
+// the list build, also used when the int32 Verlet rows are wanted (chem_get_verlet_pairs); the production instantiation carries none of it (their uniform branches in the peel loop cost 7 % of the
 // launch: 386 -> 360 us)
 template <typename R, int BS, bool DIAG = false>
 __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const FusedArgs<R> a) {
@@ -2353,7 +2353,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
         if (ablate == 1) { for (int q = t; q < T.geom[4]; q += BS) a.nnh[T.geom[5] + q] = 0; }
         else
         dev_nlist_tile_f32<BS>(T, chem_dyn_lds, L, a.tago, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.nl16, a.S, a.nnh,
-                               a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, ablate);
+                               (DIAG && a.want32) ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, ablate);
       } else {
         tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
         __syncthreads();
