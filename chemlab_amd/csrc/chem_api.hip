@@ -170,7 +170,12 @@ template <typename R> struct CtxT : Ctx {
   int tile_cap = 0;       // LDS slots of one staged tile (dynamic LDS)
   size_t tile_lds_bytes() const { return (size_t)(tile_cap + 5) * sizeof(V4) + 16; }
   // the list build has its own layout of the same block (fp32: SoA groups + type masks + slice boundaries)
-  size_t list_lds_need() const { return sizeof(R) == 4 ? std::max(tile_lds_bytes(), list_lds_bytes(tile_cap, kMaxTypes)) : tile_lds_bytes(); }
+  // (fp64 builds use the fp32 list image too -- the force list may be a superset -- and need their own 32-byte-per-slot
+  //  image only where the exact int32 rows are built)
+  size_t list_lds_need(bool exact_rows = true) const {
+    const size_t lb = list_lds_bytes(tile_cap, kMaxTypes);
+    return (sizeof(R) == 4 || exact_rows) ? std::max(tile_lds_bytes(), lb) : lb;
+  }
   hipStream_t stream = nullptr;
   int n = 0;
   DBuf<V4> x4, v4, f4, x4o, v4o, tab, x0;
@@ -181,7 +186,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot, cell_n, bucket; int bcap = 0; DBuf<GridBar> gbar;
   DBuf<int> tile_cnt, tile_off;   // reaction scan on tiles: candidates per tile, their offsets
   DBuf<int4> bwork, bj; int nb_owner = 0; bool bwork_dirty = true;   // bonded work list (see dev_bonded_prep)
-  int fused_grid = 0, fused_par = 0, seg_shift = 0, tseg_shift = 0; bool use_fused = false;
+  int fused_grid = 0, fused_grid_diag = 0, fused_par = 0, seg_shift = 0, tseg_shift = 0; bool use_fused = false;
   DBuf<int> nlist, nn, nnh;
   DBuf<unsigned short> nl16;
   DBuf<TileLDS<R>> tdesc;
@@ -324,12 +329,17 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rebuild_fused<R, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()));
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, list_lds_need()) != hipSuccess || per_cu < 1) return;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, list_lds_need(false)) != hipSuccess || per_cu < 1) return;
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
     int g = std::min(per_cu * prop.multiProcessorCount, 1024) / 8 * 8;
     if (g < 8) return;
     fused_grid = g;
+    // the diagnostic instantiation (stamps, int32 rows) has its own resource usage and, in fp64, the larger LDS block
+    int per_cu_d = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_d, reinterpret_cast<const void*>(&k_rebuild_fused<R, 512, true>), 512, list_lds_need(true)) != hipSuccess || per_cu_d < 1) return;
+    fused_grid_diag = std::min(std::min(per_cu_d * prop.multiProcessorCount, 1024) / 8 * 8, fused_grid);
+    if (fused_grid_diag < 8) return;
     auto shift_for = [&](int nitem, int lo, int maxseg) { int sh = lo; while (((nitem + (1 << sh) - 1) >> sh) > maxseg) ++sh; return sh; };
     // cell segments: 64 cells (the prefix inside a segment is one wave reduction in the sort phase), more when that
     // would give more than 1024 segments; tile segments: <= 1024 of them
@@ -358,8 +368,8 @@ template <typename R> struct CtxT : Ctx {
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
     a.wgst = dbg_on && wgst.p ? wgst.p : nullptr;
     a.bstart = bstart.p; a.bent = bent.p; a.bwork = bwork.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
-    if (dbg_on || want32) hipLaunchKernelGGL((k_rebuild_fused<R, 512, true>), dim3(fused_grid), dim3(512), list_lds_need(), stream, a);
-    else hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), list_lds_need(), stream, a);
+    if (dbg_on || want32) hipLaunchKernelGGL((k_rebuild_fused<R, 512, true>), dim3(fused_grid_diag), dim3(512), list_lds_need(true), stream, a);
+    else hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), list_lds_need(false), stream, a);
     fused_par ^= 1;
   }
 
@@ -712,7 +722,7 @@ template <typename R> struct CtxT : Ctx {
     if (use_tiles) {
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c, (const int*)cell_sub.p);
       hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
-      hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), list_lds_need(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
+      hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), list_lds_need(want32), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
                          excl_start.p, excl_list.p, has_excl, act, ntypes, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
     } else if (box.nc[0] > 0)
       hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,

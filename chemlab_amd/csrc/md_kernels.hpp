@@ -1191,9 +1191,12 @@ __device__ __forceinline__ void list_stage_clear(unsigned char* lds, const ListL
   for (int k = threadIdx.x; k < ntypes * L.nwords; k += BS) tm[k] = 0u;
 }
 // ... and stages coordinates, type masks and slice boundaries of the tile described by T (caller synchronises afterwards)
-template <int BS>
-__device__ __forceinline__ void list_stage_f32(TileLDS<float>& T, unsigned char* lds, const ListLDS& L, const int CAP,
-                                               const float4* __restrict__ x4, const ActMask& act, int ntypes) {
+// RS = precision of the particle arrays and tile tables: the image itself is always fp32 (tile-local coordinates, the
+// subtraction of the stencil corner done in RS) -- the force list it yields may be a superset, so the fp64 build uses
+// this list build too and keeps its exact fp64 one for the int32 Verlet rows only
+template <typename RS, int BS>
+__device__ __forceinline__ void list_stage_f32(TileLDS<RS>& T, unsigned char* lds, const ListLDS& L, const int CAP,
+                                               const Vec4<RS>* __restrict__ x4, const ActMask& act, int ntypes) {
   constexpr int NW = BS / 64;
   // explicit LDS address space: through a generic pointer these become flat_* accesses (and flat atomics)
   CHEM_LDS unsigned char* const l3 = (CHEM_LDS unsigned char*)lds;
@@ -1223,9 +1226,9 @@ __device__ __forceinline__ void list_stage_f32(TileLDS<float>& T, unsigned char*
         const int g = T.cellg[r][k] + (e - T.celloff[r][k]);
         const int dst = o0 + e;
         if (dst < CAP) {
-          const float4 p = x4[g];
+          const Vec4<RS> p = x4[g];
           CHEM_LDS float* grp = img + (dst >> 2) * kGrpF + (dst & 3);
-          const float u = (p.x + T.cellshx[r][k]) - T.org[0], v = (p.y + T.rowshy[r]) - T.org[1], w_ = (p.z + T.rowshz[r]) - T.org[2];
+          const float u = (float)((p.x + T.cellshx[r][k]) - T.org[0]), v = (float)((p.y + T.rowshy[r]) - T.org[1]), w_ = (float)((p.z + T.rowshz[r]) - T.org[2]);
           grp[0] = u; grp[4] = v; grp[8] = w_; grp[12] = fmaf(u, u, fmaf(v, v, w_ * w_));   // (explicit: the same rounding in every kernel this is inlined into)
           tj = (int)p.w & 15;
         }
@@ -1411,11 +1414,11 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
 // 45 KB image allows).  A test leaves its result in the sign bit of rl^2 - r^2, which one v_alignbit per candidate
 // shifts into the segment's miss mask.  Hits surviving the type mask (and, located as slots, the self pair and up to
 // four excluded partners) are peeled off and appended to the lane's 16-byte chunk register.
-template <int BS>
-__device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsigned char* lds, const ListLDS& L, const int* tag, const float rl2,
+template <typename RS, int BS>
+__device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigned char* lds, const ListLDS& L, const int* tag, const float rl2,
                                                    const int* excl_start, const int* excl_list, const int has_excl,
                                                    unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl,
-                                                   const Box<float>* bx, const int* rtag, const float4* x4, const int ablate = 0) {
+                                                   const Box<RS>* bx, const int* rtag, const Vec4<RS>* x4, const int ablate = 0) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const volatile f32x4 lds_f32x4;   // volatile: keeps the 16-byte reads and their order
@@ -1463,7 +1466,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
         if (e0 + k < e1) {
           const int g = rtag[excl_list[e0 + k]];
           if (g >= 0) {
-            const float4 xg = x4[g];
+            const Vec4<RS> xg = x4[g];
             int cx = (int)(xg.x * bx->cell_inv[0]), cy = (int)(xg.y * bx->cell_inv[1]), cz = (int)(xg.z * bx->cell_inv[2]);
             cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx); cy = cy >= ny ? ny - 1 : (cy < 0 ? 0 : cy); cz = cz >= nz ? nz - 1 : (cz < 0 ? 0 : cz);
             int kx = cx - (org & 1023) + 1, ky = cy - ((org >> 10) & 1023) + 1, kz = cz - (org >> 20) + 1;
@@ -1497,11 +1500,12 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
     // home particle from that row's slab), so only x within sqrt(rl^2 - ddy^2 - ddz^2) can be a neighbour -- 46 % of the
     // 3-cell run on average.  `weps` absorbs every rounding difference between the binning arithmetic and this one (the
     // slices only prune, the distance test decides membership).
-    const float weps = T.clen[0] * 2e-4f;
-    const float ylo = (float)(ly + 1) * T.clen[1], zlo = (float)(lz + 1) * T.clen[2];
-    const float dylo = fmaxf(xiy - ylo - weps, 0.f), dyhi = fmaxf(ylo + T.clen[1] - xiy - weps, 0.f);
-    const float dzlo = fmaxf(xiz - zlo - weps, 0.f), dzhi = fmaxf(zlo + T.clen[2] - xiz - weps, 0.f);
-    const float sxi = xix * T.subinv;
+    const float clen0 = (float)T.clen[0], clen1 = (float)T.clen[1], clen2 = (float)T.clen[2], subinv = (float)T.subinv;
+    const float weps = clen0 * 2e-4f;
+    const float ylo = (float)(ly + 1) * clen1, zlo = (float)(lz + 1) * clen2;
+    const float dylo = fmaxf(xiy - ylo - weps, 0.f), dyhi = fmaxf(ylo + clen1 - xiy - weps, 0.f);
+    const float dzlo = fmaxf(xiz - zlo - weps, 0.f), dzhi = fmaxf(zlo + clen2 - xiz - weps, 0.f);
+    const float sxi = xix * subinv;
     const int fmin = lx * NSUB, fmax = (lx + 3) * NSUB - 1;
     auto window = [&](int dzy, int& a, int& b) {
       const int dz = dzy / 3, dy = dzy - 3 * dz;
@@ -1510,7 +1514,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<float>& T, unsi
       const float w2 = rl2 - ddy * ddy - ddz * ddz;
       int f_lo = fmin, f_hi = fmax;
       if (!nowin) {
-        const float ws = (__builtin_amdgcn_sqrtf(fmaxf(w2, 0.f)) + weps) * T.subinv;
+        const float ws = (__builtin_amdgcn_sqrtf(fmaxf(w2, 0.f)) + weps) * subinv;
         const int g_lo = (int)(sxi - ws), g_hi = (int)(sxi + ws);     // truncation == floor where it matters (clamped at >= fmin)
         f_lo = g_lo > fmin ? g_lo : fmin; f_lo = f_lo < fmax ? f_lo : fmax; f_hi = g_hi < fmax ? g_hi : fmax; f_hi = f_hi > fmin ? f_hi : fmin;
       }
@@ -1631,13 +1635,15 @@ __global__ __launch_bounds__(BS, 4) void k_nlist_tiles(int ntiles, int CAP, cons
     const int tile = xcd_remap(vb, ntiles);     // gridDim.x is a multiple of 8: vb % 8 == blockIdx.x % 8
     __syncthreads();
     tile_load_desc<R>(T, desc, tile);
-    if constexpr (sizeof(R) == 4) list_stage_clear<BS>(chem_dyn_lds, list_lds_layout(CAP, ntypes), ntypes);
+    const bool f32list = sizeof(R) == 4 || !nlist;      // fp64: the exact list build only where the int32 rows are wanted
+    if (f32list) list_stage_clear<BS>(chem_dyn_lds, list_lds_layout(CAP, ntypes), ntypes);
     __syncthreads();
-    if constexpr (sizeof(R) == 4) {
+    if (f32list) {
       const ListLDS L = list_lds_layout(CAP, ntypes);
-      list_stage_f32<BS>(T, chem_dyn_lds, L, CAP, x4, act, ntypes);
+      list_stage_f32<R, BS>(T, chem_dyn_lds, L, CAP, x4, act, ntypes);
       __syncthreads();
-      dev_nlist_tile_f32<BS>(T, chem_dyn_lds, L, tag, rl2, excl_start, excl_list, has_excl, nl16, S16, nnh, nlist, S, nn, ctl, nullptr, nullptr, x4);
+      dev_nlist_tile_f32<R, BS>(T, chem_dyn_lds, L, tag, (float)rl2, excl_start, excl_list, has_excl, nl16, S16, nnh, nlist, S, nn, ctl,
+                                (const Box<R>*)nullptr, nullptr, x4);
     } else {
       tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
       __syncthreads();
@@ -2334,7 +2340,8 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
       if (w == BS / 64 - 1) {
         for (int j = ((tile >> a.tseg_shift) << a.tseg_shift) + lane; j < tile; j += 64) hb_part += a.tn[j];
       }
-      if constexpr (sizeof(R) == 4) list_stage_clear<BS>(chem_dyn_lds, list_lds_layout(a.CAP, a.ntypes), a.ntypes);   // (tile_tables synchronises)
+      const bool f32list = sizeof(R) == 4 || !(DIAG && a.want32);   // fp64: the exact list build only where the int32 rows are wanted
+      if (f32list) list_stage_clear<BS>(chem_dyn_lds, list_lds_layout(a.CAP, a.ntypes), a.ntypes);   // (tile_tables synchronises)
       tile_tables<R>(T, a.CAP, tile, a.cell_start, a.box, ctl, a.cell_sub);      // ends with a workgroup barrier
       if (w == BS / 64 - 1) {
         for (int o = 32; o > 0; o >>= 1) hb_part += __shfl_xor(hb_part, o);
@@ -2346,13 +2353,13 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
         int* dst = reinterpret_cast<int*>(&a.desc[tile]);
         for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
       }
-      if constexpr (sizeof(R) == 4) {
+      if (f32list) {
         const ListLDS L = list_lds_layout(a.CAP, a.ntypes);
-        list_stage_f32<BS>(T, chem_dyn_lds, L, a.CAP, a.x4o, a.act, a.ntypes);
+        list_stage_f32<R, BS>(T, chem_dyn_lds, L, a.CAP, a.x4o, a.act, a.ntypes);
         __syncthreads();
         if (ablate == 1) { for (int q = t; q < T.geom[4]; q += BS) a.nnh[T.geom[5] + q] = 0; }
         else
-        dev_nlist_tile_f32<BS>(T, chem_dyn_lds, L, a.tago, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.nl16, a.S, a.nnh,
+        dev_nlist_tile_f32<R, BS>(T, chem_dyn_lds, L, a.tago, (float)a.rl2, a.excl_start, a.excl_list, a.has_excl, a.nl16, a.S, a.nnh,
                                (DIAG && a.want32) ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, ablate);
       } else {
         tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
