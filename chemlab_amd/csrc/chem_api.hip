@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <memory>
 #include <thread>
+#include <mutex>
 #include <exception>
 #include <tuple>
 
@@ -169,6 +170,8 @@ template <typename R> struct CtxT : Ctx {
   bool state_mirror_stale = false;   // top.state lags the device after reaction steps
   int tile_cap = 0;       // LDS slots of one staged tile (dynamic LDS)
   size_t tile_lds_bytes() const { return (size_t)(tile_cap + 5) * sizeof(V4) + 16; }
+  // force kernel: fp64 stages 24-byte slots + type bytes (two workgroups per CU instead of one)
+  size_t pair_lds_bytes() const { return sizeof(R) == 8 ? (size_t)(tile_cap + 5) * 25 + 64 : tile_lds_bytes(); }
   // the list build has its own layout of the same block (fp32: SoA groups + type masks + slice boundaries)
   // (fp64 builds use the fp32 list image too -- the force list may be a superset -- and need their own 32-byte-per-slot
   //  image only where the exact int32 rows are built)
@@ -945,7 +948,7 @@ template <typename R> struct CtxT : Ctx {
       if (pair_subset == 1) { ts = TileSub{ntxy, ntiles - 2 * ntxy, 0}; nsub = ntiles - 2 * ntxy; }
       else if (pair_subset == 2) { ts = TileSub{0, ntxy, ntiles - ntxy}; nsub = 2 * ntxy; }
       if (nsub <= 0) return 0;
-#define LTD(T, M, B, D) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M, D>), dim3(nsub), dim3(B), tile_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
+#define LTD(T, M, B, D) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M, D>), dim3(nsub), dim3(B), pair_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
                                  nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, pair_guard, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr, ts, pair_da)
 #define LT(T, M, B) LTD(T, M, B, false)
       // diagnostics (options debug_stamps / ablate): one instantiation, one lane per particle, 512 threads
@@ -1743,6 +1746,16 @@ extern "C" {
 int chem_abi_version(void) { return CHEM_ABI_VERSION; }
 
 chem_ctx* chem_create(int device_id, int precision) {
+  // an exception that escapes a helper thread or a destructor ends the process: say what it was before it does
+  static std::once_flag term_once;
+  std::call_once(term_once, [] {
+    std::set_terminate([] {
+      try { if (auto e = std::current_exception()) std::rethrow_exception(e); fprintf(stderr, "[libchem_mi355] std::terminate without an active exception (a joinable std::thread destroyed?)\n"); }
+      catch (const std::exception& ex) { fprintf(stderr, "[libchem_mi355] std::terminate: uncaught exception: %s\n", ex.what()); }
+      catch (...) { fprintf(stderr, "[libchem_mi355] std::terminate: uncaught exception of unknown type\n"); }
+      std::abort();
+    });
+  });
   try {
     if (precision != CHEM_PREC_F32 && precision != CHEM_PREC_F64) throw ChemError(CHEM_EINVAL, "precision must be 32 or 64");
     int ndev = 0;

@@ -1062,13 +1062,24 @@ __device__ __forceinline__ void tile_load_desc(TileLDS<R>& T, const TileLDS<R>* 
 // kernel), 1: .w = (global index << 5 | type) (list build; bit 4 stays clear so that v_bfe can take .w as its offset).  Caller synchronises afterwards.
 // All global loads of a wave are issued before the first LDS write so that the staging costs one
 // memory latency, not one per row chunk.
-template <typename R, int BS, bool LEAN = false>
+// D3 (fp64 force kernel): 24-byte slots (x, y, z) with the types in a byte array behind the image instead of 32-byte
+// (x, y, z, type) slots -- 70 KB instead of 90 KB at C5, i.e. two workgroups per CU instead of one
+template <typename R> __device__ __forceinline__ unsigned char* d3_types(Vec4<R>* sx, int CAP) { return reinterpret_cast<unsigned char*>(sx) + (size_t)(CAP + 1) * 24; }
+template <typename R, bool D3>
+__device__ __forceinline__ void slot_store(Vec4<R>* const sx, const int CAP, int dst, const Vec4<R>& p) {
+  if constexpr (D3) {
+    R* s3 = reinterpret_cast<R*>(sx) + 3 * dst;
+    s3[0] = p.x; s3[1] = p.y; s3[2] = p.z;
+    d3_types<R>(sx, CAP)[dst] = (unsigned char)(int)p.w;
+  } else sx[dst] = p;
+}
+template <typename R, int BS, bool LEAN = false, bool D3 = false>
 __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx, const int CAP,
                                           const Vec4<R>* __restrict__ x4, int wmode) {
   constexpr int NW = BS / 64, RPW = (NROW + NW - 1) / NW;
   const int t = threadIdx.x;
   const int w = t >> 6, l = t & 63;
-  if (t == 0) sx[T.geom[3]] = mk4<R>((R)1e18, (R)1e18, (R)1e18, (R)0);
+  if (t == 0) slot_store<R, D3>(sx, CAP, T.geom[3], mk4<R>((R)1e18, (R)1e18, (R)1e18, (R)0));
   if constexpr (LEAN) {
     // register-lean variant (list build: staging is <2 % of the tile's time, occupancy matters more)
     for (int r = w; r < NROW; r += NW) {
@@ -1083,7 +1094,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
           Vec4<R> p = x4[g];
           p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
           if (wmode) p.w = idx_as_real((g << 5) | (int)p.w, (R)0);
-          sx[dst] = p;
+          slot_store<R, D3>(sx, CAP, dst, p);
         }
       }
     }
@@ -1121,7 +1132,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
           Vec4<R> p = pv[rr][c];
           p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
           if (wmode) p.w = idx_as_real((pg[rr][c] << 5) | (int)p.w, (R)0);
-          sx[dst] = p;
+          slot_store<R, D3>(sx, CAP, dst, p);
         }
       }
     }
@@ -1139,7 +1150,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
         Vec4<R> p = x4[g];
         p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
         if (wmode) p.w = idx_as_real((g << 5) | (int)p.w, (R)0);
-        sx[dst] = p;
+        slot_store<R, D3>(sx, CAP, dst, p);
       }
     }
   }
@@ -1702,6 +1713,11 @@ __device__ __forceinline__ float4 lds_gather4(const float4* sx, unsigned int slo
   return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ double4 lds_gather4(const double4* sx, unsigned int slot) { return sx[slot]; }
+// fp64 force kernel, 24-byte slots: coordinates only (the type is read from the byte array where a mode needs it)
+__device__ __forceinline__ double4 lds_gather3d(const double4* sx, unsigned int slot) {
+  const double* s3 = reinterpret_cast<const double*>(sx) + 3 * slot;
+  return make_double4(s3[0], s3[1], s3[2], 0.0);
+}
 template <typename R> __device__ __forceinline__ Vec4<R> lds_gather4(const Vec4<R>* sx, unsigned int slot) { return lds_gather4(sx, slot); }
 
 struct UniLJ { float rc2, lj1, lj2, pad; double drc2, dlj1, dlj2; };   // all listed pairs share one LJ parameter set
@@ -1719,11 +1735,12 @@ struct TileSub { int base1, n1, base2; };
 // halo exchange and the forces.  The accumulated distance is double-buffered by step parity (read [par], written [par^1]).
 struct DecideArgs { const double* gathered; int n; volatile int* host_flag; int ticket, par, criterion; };
 
+// (fp64: the 32-byte-per-slot image allows one or two workgroups per CU anyway -- 128 registers instead of 80 and spills)
 // DIAG = true: diagnostic instantiation with per-block phase stamps (`dbg`) and early exits (`ablate`: 1 stop after
 // staging, 2 skip staging, 3 descriptor only, 4 dispatch only); the production instantiation carries neither.
 // guard != 0: speculative launch of the decomposed path -- leave at once while a rebuild is pending.
 template <typename R, int TPP, bool ENERGY, int BS, int MODE, bool DIAG = false>
-__global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
+__global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536) / 256) void k_pair_tiles(int ntiles, int CAP, const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4,
                                                    const TileLDS<R>* __restrict__ desc, const unsigned short* __restrict__ nl16,
                                                    const int* __restrict__ nnh, int S16,
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
@@ -1785,7 +1802,8 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
       pkv[c] = (sub + c * TPP) * 8 < S16 ? nt_load_u4(&reg[(size_t)(sub + c * TPP) * nhome + q]) : make_uint4(0, 0, 0, 0);
   };
   if (slice < nhome) locate(slice);
-  if (!DIAG || ablate != 2) tile_fill<R, BS>(T, sx, CAP, x4, 0);
+  constexpr bool D3 = sizeof(R) == 8;     // fp64: 24-byte slots + type bytes (see tile_fill)
+  if (!DIAG || ablate != 2) tile_fill<R, BS, false, D3>(T, sx, CAP, x4, 0);
   __syncthreads();
   if (DIAG && ablate == 1) return;   // diagnostic: staging only
   if (DIAG && dbg) st2 = wall_clock64();
@@ -1795,7 +1813,8 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
     R fx = 0, fy = 0, fz = 0;
     if (q0 > 0) { p = -1; if (q < nhome) locate(q); }
     if (p >= 0) {
-      const Vec4<R> xi = sx[hslot];
+      Vec4<R> xi;
+      if constexpr (D3) { xi = lds_gather3d(sx, hslot); xi.w = (R)d3_types<R>(sx, CAP)[hslot]; } else xi = sx[hslot];
       const int pbase = (int)xi.w * ntypes;
       auto do_chunk = [&](const uint4 pk) {
         const unsigned int wds[4] = {pk.x, pk.y, pk.z, pk.w};
@@ -1803,7 +1822,11 @@ __global__ __launch_bounds__(BS, (BS == 1024 ? 2048 : 1536) / 256) void k_pair_t
         for (int h = 0; h < 2; ++h) {
           Vec4<R> xs[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) xs[u] = lds_gather4<R>(sx, (wds[2 * h + (u >> 1)] >> ((u & 1) * 16)) & 0xffff);   // 4 LDS gathers in flight
+          for (int u = 0; u < 4; ++u) {   // 4 LDS gathers in flight
+            const unsigned int sl = (wds[2 * h + (u >> 1)] >> ((u & 1) * 16)) & 0xffff;
+            if constexpr (D3) { xs[u] = lds_gather3d(sx, sl); if (MODE != 2 || ENERGY) xs[u].w = (R)d3_types<R>(sx, CAP)[sl]; }
+            else xs[u] = lds_gather4<R>(sx, sl);
+          }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const Vec4<R> xj = xs[u];
