@@ -2,7 +2,7 @@
 // back end consumes -- from a plain-text script on stdin and prints its state, so that a pytest can
 // compare it with an independent Python model.  Not part of the product library.
 //   n <N>; type <tag> <t>; res <tag> <r>; list <arity> [typed]; reg <list> <t...>; bond <list> <a> <b> (initial, graph only)
-//   newbonds <k> <a b>...  -> list_insert into list 0 + on_new_bonds;  dump
+//   newbonds <k> <a b>...  -> list_insert into list 0 + on_new_bonds;  reserve <list> <keys> (hash set sized up front);  dump
 #include <cstdio>
 #include <iostream>
 #include <sstream>
@@ -21,6 +21,7 @@ int main() {
     else if (cmd == "res") { int a, b; is >> a >> b; t.res_id[a] = b; }
     else if (cmd == "list") { int ar; is >> ar; HostList l; l.arity = ar; l.kind = 1; l.has_plain = true; t.lists.push_back(l); }
     else if (cmd == "reg") { int li; is >> li; std::array<int, 4> r{-1, -1, -1, -1}; for (int k = 0; k < t.lists[li].arity; ++k) is >> r[k]; t.lists[li].registered.push_back(r); }
+    else if (cmd == "reserve") { int li; long long k; is >> li >> k; t.lists[li].seen.reserve((size_t)k); t.lists[li].ent.reserve(t.lists[li].ent.size() + 2 * (size_t)k); }   // what a run with reactions does up front
     else if (cmd == "bond") { int li; int32_t p[2]; is >> li >> p[0] >> p[1]; if (t.list_insert(t.lists[li], p)) { t.graph_add(p[0], p[1]); t.exclude(p[0], p[1]); } }
     else if (cmd == "newbonds") {
       int k; is >> k; std::vector<std::pair<int32_t, int32_t>> nb;

@@ -65,11 +65,13 @@ def model(n, types, res, init_bonds, reg, batches):
     return bonds, angles, [sorted(e) for e in excl], list(zip(res, mol))
 
 
-def run_harness(exe, n, types, res, init_bonds, reg, batches):
+def run_harness(exe, n, types, res, init_bonds, reg, batches, reserve_after=None):
     lines = ["n %d" % n] + ["type %d %d" % (i, t) for i, t in enumerate(types)] + ["res %d %d" % (i, r) for i, r in enumerate(res)]
     lines += ["list 2", "list 3"] + ["reg 1 %d %d %d" % tuple(r) for r in reg]
     lines += ["bond 0 %d %d" % b for b in init_bonds]
-    for batch in batches:
+    for k, batch in enumerate(batches):
+        if reserve_after is not None and k == reserve_after:
+            lines.append("reserve 0 %d" % (50 * n))           # re-hash of a populated set into a table sized for a whole run
         lines.append("newbonds %d " % len(batch) + " ".join("%d %d" % b for b in batch))
     lines.append("dump")
     out = subprocess.run([exe], input="\n".join(lines) + "\n", capture_output=True, text=True, check=True).stdout.splitlines()
@@ -114,3 +116,24 @@ def test_topology_manager_against_python_model(harness, seed):
         want = ["(%d %d 0 s0 m%d)" % (a, b, (a, b).index(t)) for a, b in bonds if t in (a, b)]
         want += ["(%d %d %d s1 m%d)" % (a, b, c, (a, b, c).index(t)) for a, b, c in angles if t in (a, b, c)]
         assert row.replace(") (", ")|(").strip().split("|") == want if want else row.strip() == ""
+
+
+@pytest.mark.parametrize("reserve_after", [0, 2])
+def test_reserving_the_bond_hash_set_changes_nothing(harness, reserve_after):
+    """chem_run sizes the de-duplication set of the reaction bond list for one bond per particle before the first
+    reaction step (a re-hash per doubling cost milliseconds mid-run): same lists, exclusions, labels and CSR whether the
+    set is re-hashed empty, populated, or never."""
+    rng = np.random.default_rng(7)
+    n = 90
+    types = rng.integers(0, 3, n).tolist()
+    res = (np.arange(n) // 3 + 1).tolist()
+    init = [(3 * k, 3 * k + 1) for k in range(n // 3)]
+    reg = [(0, 1, 2), (1, 1, 1)]
+    batches = []
+    for _ in range(5):
+        perm = rng.permutation(n)[:24]
+        batches.append([(int(perm[2 * k]), int(perm[2 * k + 1])) for k in range(12)])
+    batches.append(batches[1][:6] + [(b, a) for a, b in batches[2][:6]])      # duplicates, also reversed: must be rejected either way
+    ref = run_harness(harness, n, types, res, init, reg, batches)
+    got = run_harness(harness, n, types, res, init, reg, batches, reserve_after=reserve_after)
+    assert got == ref
