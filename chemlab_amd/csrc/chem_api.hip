@@ -132,6 +132,7 @@ struct Ctx {
   int opt_time_pair = 0;    // HIP-event timing of every N-th pair-force launch (0 = off)
   int64_t pair_launch_no = 0;
   int opt_fuse = 1;         // fused integrate2+integrate1
+  int opt_lpt = 1;          // descriptors of the fused rebuild in largest-tile-first order per XCD range (force launch tail)
   int opt_dd_merge = 1;     // decomposed path: displacement fold in the integrate kernel, decision in the force kernel (no one-block launches)
   int opt_ablate_list = 0;  // diagnostics (with debug_stamps): parts of the list build left out, see tools/rebuild_stamps.py
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
@@ -319,6 +320,7 @@ template <typename R> struct CtxT : Ctx {
     ntiles = use_tiles ? ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY) * (((dd_on ? ncz : box.nc[2]) + HZ - 1) / HZ) : 0;
     alloc_lists();
     setup_fused();
+    setup_tile_order();
     HIPCHK(hipStreamSynchronize(stream));
     geom_dirty = false; resort = true;
   }
@@ -358,6 +360,25 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipMemsetAsync(seg_tot.p, 0, sizeof(int) * 1024, stream));
     use_fused = true;
   }
+  DBuf<int> tile_pos;
+  void setup_tile_order() {
+    if (!use_tiles || dd_on || ntiles < 8) { tile_pos.free(); return; }
+    const int ntx = (box.nc[0] + HX - 1) / HX, nty = (box.nc[1] + HY - 1) / HY;
+    auto home_cells = [&](int tile) {
+      const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+      return std::min(HX, box.nc[0] - tx * HX) * std::min(HY, box.nc[1] - ty * HY) * std::min(HZ, box.nc[2] - tz * HZ);
+    };
+    std::vector<int> ord(ntiles), pos(ntiles);
+    const int q = ntiles >> 3, r = ntiles & 7;
+    for (int x = 0, off = 0; x < 8; ++x) {      // the contiguous ranges xcd_remap hands to the XCDs
+      const int cnt = q + (x < r ? 1 : 0);
+      for (int k = 0; k < cnt; ++k) ord[off + k] = off + k;
+      std::stable_sort(ord.begin() + off, ord.begin() + off + cnt, [&](int a_, int b_) { return home_cells(a_) > home_cells(b_); });
+      for (int k = 0; k < cnt; ++k) pos[ord[off + k]] = off + k;
+      off += cnt;
+    }
+    tile_pos.upload(pos, stream);
+  }
   void launch_rebuild_fused() {
     FusedArgs<R> a{};
     a.n = n; a.ncell = box.ncell; a.ntiles = ntiles; a.CAP = tile_cap; a.S = S; a.has_excl = has_excl; a.criterion = opt_criterion;
@@ -367,6 +388,7 @@ template <typename R> struct CtxT : Ctx {
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
     a.cell_cnt = cell_cnt.p; a.cell_of = cell_of.p; a.slot_of = slot_of.p; a.cell_start = cell_start.p; a.cell_loc = cell_loc.p;
     a.cell_sub = cell_sub.p; a.cell_n = cell_n.p; a.bucket = bucket.p; a.bcap = bcap; a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
+    a.tile_pos = opt_lpt ? tile_pos.p : nullptr;
     a.desc = tdesc.p; a.excl_start = excl_start.p; a.excl_list = excl_list.p; a.nl16 = nl16.p; a.nnh = nnh.p; a.nlist = nlist.p; a.nn = nn.p;
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
     a.wgst = dbg_on && wgst.p ? wgst.p : nullptr;
@@ -2119,6 +2141,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
   else if (k == "ablate_list") CTX.opt_ablate_list = (int)value;
   else if (k == "dd_merge") CTX.opt_dd_merge = value != 0;
+  else if (k == "lpt_tiles") { CTX.opt_lpt = value != 0; CTX.resort = true; }
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else if (k == "fused_rebuild") { CTX.opt_fused = value != 0; CTX.geom_dirty = true; }
   else if (k == "overlap_halo") CTX.opt_overlap = value < 0 ? -1 : (value != 0 ? 1 : 0);

@@ -2185,6 +2185,8 @@ template <typename R> struct FusedArgs {
   int *tag, *tago, *rtag; int4 *img4, *img4o;
   int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot, *cell_sub, *cell_n, *bucket; int bcap;
   TileLDS<R>* desc; const int *excl_start, *excl_list;
+  const int* tile_pos;   // where the descriptor of tile t goes: inside every XCD's range the full-size tiles first, the short edge
+                         // tiles last, so that the one-shot force launch (workgroup v reads desc[xcd_remap(v)]) ends on short blocks
   unsigned short* nl16; int *nnh, *nlist, *nn;
   unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
   const int* bstart; const BondedEntry* bent; int4 *bwork, *bj; int nbent;
@@ -2373,7 +2375,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
       __syncthreads();
       {   // the descriptor every force launch until the next rebuild reads
         const int* src = reinterpret_cast<const int*>(&T);
-        int* dst = reinterpret_cast<int*>(&a.desc[tile]);
+        int* dst = reinterpret_cast<int*>(&a.desc[a.tile_pos ? a.tile_pos[tile] : tile]);
         for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
       }
       if (f32list) {
