@@ -360,9 +360,9 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipMemsetAsync(seg_tot.p, 0, sizeof(int) * 1024, stream));
     use_fused = true;
   }
-  DBuf<int> tile_pos;
+  DBuf<int> tile_pos, tile_ord;
   void setup_tile_order() {
-    if (!use_tiles || dd_on || ntiles < 8) { tile_pos.free(); return; }
+    if (!use_tiles || dd_on || ntiles < 8) { tile_pos.free(); tile_ord.free(); return; }
     const int ntx = (box.nc[0] + HX - 1) / HX, nty = (box.nc[1] + HY - 1) / HY;
     auto home_cells = [&](int tile) {
       const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
@@ -377,7 +377,7 @@ template <typename R> struct CtxT : Ctx {
       for (int k = 0; k < cnt; ++k) pos[ord[off + k]] = off + k;
       off += cnt;
     }
-    tile_pos.upload(pos, stream);
+    tile_pos.upload(pos, stream); tile_ord.upload(ord, stream);
   }
   void launch_rebuild_fused() {
     FusedArgs<R> a{};
@@ -388,7 +388,7 @@ template <typename R> struct CtxT : Ctx {
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
     a.cell_cnt = cell_cnt.p; a.cell_of = cell_of.p; a.slot_of = slot_of.p; a.cell_start = cell_start.p; a.cell_loc = cell_loc.p;
     a.cell_sub = cell_sub.p; a.cell_n = cell_n.p; a.bucket = bucket.p; a.bcap = bcap; a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
-    a.tile_pos = opt_lpt ? tile_pos.p : nullptr;
+    a.tile_pos = opt_lpt ? tile_pos.p : nullptr; a.tile_ord = opt_lpt ? tile_ord.p : nullptr;
     a.desc = tdesc.p; a.excl_start = excl_start.p; a.excl_list = excl_list.p; a.nl16 = nl16.p; a.nnh = nnh.p; a.nlist = nlist.p; a.nn = nn.p;
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
     a.wgst = dbg_on && wgst.p ? wgst.p : nullptr;

@@ -2185,6 +2185,7 @@ template <typename R> struct FusedArgs {
   int *tag, *tago, *rtag; int4 *img4, *img4o;
   int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot, *cell_sub, *cell_n, *bucket; int bcap;
   TileLDS<R>* desc; const int *excl_start, *excl_list;
+  const int* tile_ord;   // the same order as a list (inverse of tile_pos): the tile queues of the list phase hand out the full-size tiles first
   const int* tile_pos;   // where the descriptor of tile t goes: inside every XCD's range the full-size tiles first, the short edge
                          // tiles last, so that the one-shot force launch (workgroup v reads desc[xcd_remap(v)]) ends on short blocks
   unsigned short* nl16; int *nnh, *nlist, *nn;
@@ -2348,7 +2349,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
         const int cntx = q + (x < r ? 1 : 0);
         if (__hip_atomic_load(&a.gb->tq[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)cntx) continue;
         const int k = (int)atomicAdd(&a.gb->tq[x][0], 1u);
-        if (k < cntx) tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+        if (k < cntx) { tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k; if (a.tile_ord) tile = a.tile_ord[tile]; }
       }
       return tile;
     };
