@@ -377,6 +377,8 @@ template <typename R> struct CtxT : Ctx {
       for (int k = 0; k < cnt; ++k) pos[ord[off + k]] = off + k;
       off += cnt;
     }
+    // (two copies each: the rebuild kernel double-buffers them by the parity of its rebuild count and rewrites them from the home counts)
+    pos.insert(pos.end(), pos.begin(), pos.begin() + ntiles); ord.insert(ord.end(), ord.begin(), ord.begin() + ntiles);
     tile_pos.upload(pos, stream); tile_ord.upload(ord, stream);
   }
   void launch_rebuild_fused() {

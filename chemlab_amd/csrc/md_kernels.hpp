@@ -2185,8 +2185,10 @@ template <typename R> struct FusedArgs {
   int *tag, *tago, *rtag; int4 *img4, *img4o;
   int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot, *cell_sub, *cell_n, *bucket; int bcap;
   TileLDS<R>* desc; const int *excl_start, *excl_list;
-  const int* tile_ord;   // the same order as a list (inverse of tile_pos): the tile queues of the list phase hand out the full-size tiles first
-  const int* tile_pos;   // where the descriptor of tile t goes: inside every XCD's range the full-size tiles first, the short edge
+  int* tile_ord;         // the same order as a list (inverse of tile_pos): the tile queues of the list phase hand out the large tiles first.
+                         // Both arrays are double-buffered ([parity of the rebuild count][ntiles]): workgroups 0..7 rewrite the other
+                         // half from THIS rebuild's home counts (gelation makes the tiles unequal), the next rebuild uses it
+  int* tile_pos;         // where the descriptor of tile t goes: inside every XCD's range the full-size tiles first, the short edge
                          // tiles last, so that the one-shot force launch (workgroup v reads desc[xcd_remap(v)]) ends on short blocks
   unsigned short* nl16; int *nnh, *nlist, *nn;
   unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
@@ -2339,6 +2341,9 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
       __syncthreads();
     }
     const int q = a.ntiles >> 3, r = a.ntiles & 7, myx = b & 7;
+    const int lpar = a.tile_ord ? (ctl->rebuild_count & 1) : 0;      // (incremented behind the first barrier: the same for everybody here)
+    const int* const ord_r = a.tile_ord ? a.tile_ord + (size_t)lpar * a.ntiles : nullptr;
+    const int* const pos_r = a.tile_pos ? a.tile_pos + (size_t)lpar * a.ntiles : nullptr;
     int ndone = 0;
     WGST(5);
     // thread 0 claims a tile: own XCD's queue first, then the others'
@@ -2349,7 +2354,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
         const int cntx = q + (x < r ? 1 : 0);
         if (__hip_atomic_load(&a.gb->tq[x][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned int)cntx) continue;
         const int k = (int)atomicAdd(&a.gb->tq[x][0], 1u);
-        if (k < cntx) { tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k; if (a.tile_ord) tile = a.tile_ord[tile]; }
+        if (k < cntx) { tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k; if (ord_r) tile = ord_r[tile]; }
       }
       return tile;
     };
@@ -2376,7 +2381,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
       __syncthreads();
       {   // the descriptor every force launch until the next rebuild reads
         const int* src = reinterpret_cast<const int*>(&T);
-        int* dst = reinterpret_cast<int*>(&a.desc[a.tile_pos ? a.tile_pos[tile] : tile]);
+        int* dst = reinterpret_cast<int*>(&a.desc[pos_r ? pos_r[tile] : tile]);
         for (int k = t; k < (int)(sizeof(TileLDS<R>) / 4); k += BS) dst[k] = src[k];
       }
       if (f32list) {
@@ -2396,6 +2401,33 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
     }
     WGST(6);
     if (wst && t == 0) wst[7] = ndone;
+    // order of the NEXT rebuild (and of the force launches behind it): wave 0 of workgroup x < 8 sorts the tiles of XCD
+    // range x by home count, largest first -- eight classes relative to the mean, stable inside a class (ballot prefix)
+    if (a.tile_ord && b < 8 && w == 0) {
+      const int cntx = q + (b < r ? 1 : 0), off = b < r ? b * (q + 1) : r * (q + 1) + (b - r) * q;
+      int* const ord_w = a.tile_ord + (size_t)(lpar ^ 1) * a.ntiles;
+      int* const pos_w = a.tile_pos + (size_t)(lpar ^ 1) * a.ntiles;
+      const int mean4 = (int)(((long long)a.n * 4 + a.ntiles - 1) / a.ntiles);      // class = 4 tn / mean, clamped: 7 classes above 7/4 of the mean ... 0
+      auto cls_of = [&](int tile) { const int c = a.tn[tile] * 16 / (mean4 > 0 ? mean4 : 1); return 7 - (c > 7 ? 7 : c); };   // 0 = largest
+      int tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int k0 = 0; k0 < cntx; k0 += 64) {
+        const int k = k0 + lane, c = k < cntx ? cls_of(off + k) : -1;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) tot[cc] += __popcll(__ballot(c == cc));
+      }
+      int base[8]; { int acc_ = 0;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) { base[cc] = acc_; acc_ += tot[cc]; } }
+      for (int k0 = 0; k0 < cntx; k0 += 64) {
+        const int k = k0 + lane, c = k < cntx ? cls_of(off + k) : -1;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+          const unsigned long long m = __ballot(c == cc);
+          if (c == cc) { const int p_ = off + base[cc] + __popcll(m & lanemask_lt()); ord_w[p_] = off + k; pos_w[off + k] = p_; }
+          base[cc] += __popcll(m);
+        }
+      }
+    }
     // bonded work list (nothing in this launch reads it): chunks of BS particles from a queue, taken by workgroups that
     // have run out of tiles -- as a fixed share in front of the tiles it was 25 us on every workgroup's critical path,
     // here it fills the idle tail of the phase (rtag is complete since the last barrier)
