@@ -1419,10 +1419,11 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
 
 // fp32 list build of ONE tile staged by list_stage_f32 (workgroup synchronised).  Same products as dev_nlist_tile.
 // Per home particle (one lane each) and stencil row: x-window [a, b) from the slice-boundary table, then segments of
-// up to 32 candidates = 8 groups of four slots; the next group's three ds_read_b128 are issued before the current
-// one is evaluated, and the window of the NEXT row is looked up before this row's candidates are walked, so that the
-// LDS latencies hide behind arithmetic instead of adding up (the lanes are latency-bound: 24 waves per CU is all the
-// 45 KB image allows).  A test leaves its result in the sign bit of rl^2 - r^2, which one v_alignbit per candidate
+// up to 32 candidates = 8 groups of four slots, two groups per trip on ping-pong registers: the four ds_read_b128 of the
+// group after next are in flight while one is tested, and the window of the NEXT row is looked up before this row's
+// candidates are walked, so that the LDS latencies hide behind arithmetic instead of adding up (16 waves per CU: the
+// rebuild kernel runs two workgroups per CU at 128 registers).  A test (expanded form, see the layout note above)
+// leaves its result in the sign bit of rl^2 + delta - r^2, which one v_alignbit per candidate
 // shifts into the segment's miss mask.  Hits surviving the type mask (and, located as slots, the self pair and up to
 // four excluded partners) are peeled off and appended to the lane's 16-byte chunk register.
 template <typename RS, int BS>
