@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- MD steps/s of the reactive LJ melt (BASELINE.json metric) on N MI355X.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: starts the N ranks itself, as a child torch.distributed.run)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one velocity-Verlet MD step of the whole system (neighbour-list upkeep, pair and
@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--opt", action="append", default=[], help="name=value engine option (tuning)")
     p.add_argument("--no-roofline", action="store_true")
     p.add_argument("--verbose", action="store_true", help="timers to stderr")
+    p.add_argument("--rendezvous-only", action="store_true",
+                   help="N > 1: start the ranks, run the gloo rendezvous (barrier + max over ranks) and stop before any GPU work")
     return p.parse_args()
 
 
@@ -214,18 +216,46 @@ def time_reaction_step(eng, interval, ms_per_step):
     return dict(reaction_step_ms=max(0.0, 1e3 * dt - ms_per_step), reaction_events=len(eng.get_events()) - ev0, at_step=int(eng.step))
 
 
+def spawn_ranks(nranks):
+    """`python bench.py --gpus N` started plainly (no torch.distributed.run around it): this process never touches the
+    GPU -- it starts the N ranks as a CHILD process (`python -m torch.distributed.run ... bench.py <same arguments>`, one
+    rank per GPU, rendezvous on 127.0.0.1), relays the child's output (rank 0's JSON line) and exits with its code."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks),
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    res = subprocess.run(cmd, env=env)
+    return res.returncode
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if a.gpus == 1 and world == 1:
-            pass
-        else:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d, or plainly "
+                         "(python bench.py --gpus %d starts the ranks itself)" % (a.gpus, world, a.gpus, a.gpus))
     from chemlab_amd import workloads as W
 
+    if a.rendezvous_only:
+        from chemlab_amd import multigpu
+        dist = multigpu.init_process_group()
+        dist.barrier()
+        top = multigpu.max_over_ranks(dist, float(rank))
+        if rank == 0:
+            print(json.dumps(dict(rendezvous="ok", n_gpus=world, max_rank=int(top), node_grid=list(multigpu.node_grid(world)))))
+        dist.barrier()
+        return 0
     spec = W.reactive_melt(n=a.n, rho=a.rho, interval=a.interval, seed=2)
     if world > 1 or os.environ.get("CHEM_FORCE_DD"):   # CHEM_FORCE_DD: exercise the RCCL slab path with one rank
         from chemlab_amd import multigpu
@@ -294,14 +324,19 @@ def main():
         e64.close()
 
     if a.cpu_steps != 0:
-        from oracle.oracle import host_cores
+        from oracle.oracle import host_cores, lscpu_cores
         # a one-GPU box exposes every core of the host in the affinity mask but grants a 16-core share
         # (more threads than that only fight each other: 256 threads ran 3.5x SLOWER than one)
         cores = min(host_cores(), 16 * max(1, a.gpus))
         ns = a.cpu_steps if a.cpu_steps > 0 else max(8, int(round(12 * 1.0e6 / a.n * min(cores, 16) / 8.0)))
         out["cpu_baseline"] = cpu_baseline(melted, ns, cores)
+        lc = lscpu_cores()
+        out["cpu_baseline"]["host"] = dict(lscpu_logical_cpus=lc[0] if lc else None, lscpu_physical_cores=lc[1] if lc else None,
+                                           usable_cores=host_cores(), threads_used=cores)
+        out["cpu_baseline"]["sample"] += ("; host per lscpu: %s logical CPUs / %s physical cores, share granted to this job (affinity + cgroup "
+                                          "quota): %d, threads used: %d" % (lc[0] if lc else "?", lc[1] if lc else "?", host_cores(), cores))
     print(json.dumps(out))
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

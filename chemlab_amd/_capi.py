@@ -54,6 +54,17 @@ class NbChange(C.Structure):
                 ("new_mass", C.c_double), ("new_q", C.c_double)]
 
 
+class AtrpDesc(C.Structure):
+    _fields_ = [("interval", C.c_int32), ("num_particles", C.c_int32), ("select_from_all", C.c_int32), ("pad", C.c_int32),
+                ("ratio_activator", C.c_double), ("ratio_deactivator", C.c_double), ("delta_catalyst", C.c_double),
+                ("k_activate", C.c_double), ("k_deactivate", C.c_double), ("seed", C.c_uint64)]
+
+
+class AtrpStats(C.Structure):
+    _fields_ = [("step", C.c_int64), ("candidates", C.c_int64), ("selected", C.c_int64), ("activated", C.c_int64),
+                ("deactivated", C.c_int64), ("ratio_activator", C.c_double), ("ratio_deactivator", C.c_double)]
+
+
 class Event(C.Structure):
     _fields_ = [("step", C.c_int64), ("id_a", C.c_int64), ("id_b", C.c_int64),
                 ("reaction", C.c_int32), ("pad", C.c_int32), ("r2", C.c_double)]
@@ -100,6 +111,7 @@ SIGNATURES = {
     "list_set_params": (_i, [_P, _i, _i, _i, _i, _i, _pd, _i]),
     "get_list": (_i64, [_P, _i, _pi64, _i64]),
     "thermostat_langevin": (_i, [_P, _d, _d, _u64]),
+    "thermostat_langevin_types": (_i, [_P, _i, _pi32]),
     "cap_force": (_i, [_P, _d]),
     "thermostat_rescale": (_i, [_P, _i, _d, _d]),
     "thermostat_svr": (_i, [_P, _d, _d, _u64]),
@@ -107,6 +119,9 @@ SIGNATURES = {
     "reaction_init": (_i, [_P, _i, _i, _i, _u64]),
     "reaction_add": (_i, [_P, C.POINTER(ReactionDesc)]),
     "reaction_neighbour_change": (_i, [_P, C.POINTER(NbChange)]),
+    "atrp_init": (_i, [_P, C.POINTER(AtrpDesc)]),
+    "atrp_add_center": (_i, [_P, _i, _i, _i, _i, _d, _d, _i]),
+    "atrp_get_stats": (_i64, [_P, C.POINTER(AtrpStats), _i64]),
     "topology_register": (_i, [_P, _i, _i, _pi32]),
     "reactions_enable": (_i, [_P, _i]),
     "reaction_set_rate": (_i, [_P, _i, _d]),

@@ -9,6 +9,7 @@ class SetupReactions(object):
         self.name2type = topol.used_atomsym_atomtype
         self.dynamic_types = set()
         self.fpls = []
+        self.extensions_to_integrator = []
 
     def _setup_reaction_normal(self, cr, fpl):
         e, rl = self.espp, cr["reactant_list"]
@@ -43,6 +44,8 @@ class SetupReactions(object):
         cfg = self.cfg["extensions"].get(name)
         if cfg is None:
             raise RuntimeError("extension %s is not defined ([ext_%s] missing)" % (name, name))
+        if cfg.get("ext_type") == "ATRPActivator":
+            return self._setup_atrp_activator(cfg), None
         if cfg.get("ext_type") != "ChangeNeighboursProperty":
             raise NotImplementedError("reaction extension %s (%s) is outside the hot-path scope (SURVEY f-4)" % (name, cfg.get("ext_type")))
         e, n2t = self.espp, self.name2type
@@ -63,6 +66,33 @@ class SetupReactions(object):
             self.dynamic_types.update((n2t[old_type], n2t[new_type]))
         return pp, cfg.get("invoke_on", "both")
 
+    def _setup_atrp_activator(self, cfg):
+        """[ext_*] ext_type=ATRPActivator -> integrator extension (reaction_post_process.py:380-426):
+        options=`TYPE(state,A|DA)->NEWTYPE(delta);...`, flag DA marks the centres that react with the deactivator."""
+        import re
+        e, n2t = self.espp, self.name2type
+        out_prefix = getattr(self.args, "output_prefix", "sim") if self.args is not None else "sim"
+        seed = getattr(self.args, "rng_seed", 0) if self.args is not None else 0
+        act = e.integrator.ATRPActivator(self.system, int(cfg["interval"]), int(cfg["num_particles"]), float(cfg["ratio_activator"]),
+                                         float(cfg["ratio_deactivator"]), float(cfg["delta_catalyst"]), float(cfg["k_activate"]),
+                                         float(cfg["k_deactivate"]))
+        act.stats_filename = cfg.get("stats_file", "%s_%s_atrp_stats.dat" % (out_prefix, seed))
+        act.select_from_all = int(cfg.get("select_from_all", 1))
+        re_reactant = re.compile(r"(?P<name>\w+)\((?P<state>\d+),\s*(?P<flag>[AD]{1,2})\)")
+        re_product = re.compile(r"(?P<new_type>\w+)\((?P<delta>[0-9-]+)\)")
+        for opt in cfg["options"].split(";"):
+            to_process, after_process = opt.split("->")
+            reactant = re_reactant.match(to_process.strip()).groupdict()
+            product = re_product.match(after_process.strip()).groupdict()
+            if reactant["flag"] not in ("A", "DA"):
+                raise RuntimeError('Flag %s not "A" or "DA"' % reactant["flag"])
+            prop = self.topol.gt.atomtypes[product["new_type"]]
+            act.add_reactive_center(type_id=n2t[reactant["name"]], state=int(reactant["state"]), is_activator=reactant["flag"] == "DA",
+                                    new_property=e.integrator.TopologyParticleProperties(type=n2t[product["new_type"]], mass=prop["mass"], q=prop["charge"]),
+                                    delta_state=int(product["delta"]))
+            self.dynamic_types.update((n2t[reactant["name"]], n2t[product["new_type"]]))
+        return act
+
     def setup_reactions(self):
         e, g = self.espp, self.cfg["general"]
         ar = e.integrator.ChemicalReaction(self.system, self.vl, self.system.storage, self.tm, g["interval"])
@@ -70,7 +100,10 @@ class SetupReactions(object):
         if g["max_per_interval"] > 0:
             ar.max_per_interval = g["max_per_interval"]
         for gname, group in self.cfg["reactions"].items():
-            group_pp = [(name, self._setup_extension(name)) for name in group["extensions"]]
+            group_ext = [(name, self._setup_extension(name)) for name in group["extensions"]]
+            # integrator extensions (ATRPActivator) go to the driver, post-processes to the group's reactions (reaction_setup.py:470-483)
+            self.extensions_to_integrator.extend(x for _, (x, inv) in group_ext if inv is None)
+            group_pp = [(name, v) for name, v in group_ext if v[1] is not None]
             fpl = e.FixedPairList(self.system.storage)
             pot_class = getattr(e.interaction, group["potential"])
             pot = pot_class(**group["potential_options"])

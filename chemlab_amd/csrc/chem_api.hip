@@ -88,11 +88,14 @@ struct Ctx {
   std::vector<double> pos0, vel0;  // staged particle data (tag order) until first upload
   int ntypes = 1;
   HostPairPot pp[CHEM_MAX_TYPES][CHEM_MAX_TYPES];
-  bool lang = false; double kT = 0, gamma = 0; uint64_t lang_seed = 0;
+  bool lang = false; double kT = 0, gamma = 0; uint64_t lang_seed = 0; uint32_t lang_tmask = 0;
   bool react_init = false, react_on = false;
   int interval = 0, nearest = 1, max_per_interval = 0; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
   std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty (chem_reaction_neighbour_change)
+  // integrator.ATRPActivator (chem_atrp_init; reaction_post_process.py:380-426)
+  struct AtrpCenter { int type, state, is_activator, new_type, delta_state; double new_mass, new_q; };
+  bool atrp_on = false; chem_atrp_desc atrp{}; std::vector<AtrpCenter> atrp_centers; std::vector<chem_atrp_stats> atrp_stats;
   std::vector<chem_event> events;   // expanded, canonical order (filled lazily from the arena by chem_get_events)
   // event arena: SoA copy of the device records of every reaction step, appended in device order (amortised growth:
   // fresh vectors per step cost their page faults every time -- 4 ms for 2.8e5 events); blocks = (step, first index).
@@ -176,6 +179,8 @@ template <typename R> struct CtxT : Ctx {
   // the list build has its own layout of the same block (fp32: SoA groups + type masks + slice boundaries)
   // (fp64 builds use the fp32 list image too -- the force list may be a superset -- and need their own 32-byte-per-slot
   //  image only where the exact int32 rows are built)
+  static constexpr size_t kTileLdsBudget = 150 * 1024;   // of 160 KB per CU: the rest is the kernels' static __shared__ (tile tables, scan scratch)
+  size_t tile_lds_need() const { return std::max(std::max(tile_lds_bytes(), pair_lds_bytes()), list_lds_need()); }
   size_t list_lds_need(bool exact_rows = true) const {
     const size_t lb = list_lds_bytes(tile_cap, kMaxTypes);
     return (sizeof(R) == 4 || exact_rows) ? std::max(tile_lds_bytes(), lb) : lb;
@@ -312,9 +317,9 @@ template <typename R> struct CtxT : Ctx {
       const double per_cell = dd_on ? (double)nglob / ((double)box.nc[0] * box.nc[1] * nzg) : (double)n / box.ncell;
       const int need = (int)(SX * SY * SZ * per_cell * 1.12) + 64;
       tile_cap = std::max(1024, (need + 255) / 256 * 256);
-      const size_t max_lds = 150 * 1024;
-      if (tile_lds_bytes() > max_lds) use_tiles = false;   // cells too crowded: per-cell kernels
-
+      // every kernel that stages a tile must fit: the force kernel's image AND the list build's (SoA groups + type masks +
+      // slice boundaries: ~22 B per slot against 16), next to the static __shared__ of k_rebuild_fused / k_nlist_tiles
+      if (tile_lds_need() > kTileLdsBudget) use_tiles = false;   // cells too crowded: per-cell kernels
       else set_tile_lds_attr();
     }
     ntiles = use_tiles ? ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY) * (((dd_on ? ncz : box.nc[2]) + HZ - 1) / HZ) : 0;
@@ -331,8 +336,12 @@ template <typename R> struct CtxT : Ctx {
     use_fused = false;
     if (!opt_fused || !use_tiles || dd_on) return;
     const void* fn = reinterpret_cast<const void*>(&k_rebuild_fused<R, 512>);
-    HIPCHK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rebuild_fused<R, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()));
+    // (a block the device refuses leaves the fused launch off -- the unfused chain takes over -- instead of failing the set-up)
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rebuild_fused<R, 512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, list_lds_need(false)) != hipSuccess || per_cu < 1) return;
     hipDeviceProp_t prop;
@@ -514,6 +523,7 @@ template <typename R> struct CtxT : Ctx {
     for (int a = 0; a < CHEM_MAX_TYPES; ++a) for (int b = 0; b < CHEM_MAX_TYPES; ++b) if (pp[a][b].kind) nt = std::max(nt, std::max(a, b) + 1);
     for (auto& r : reactions) { nt = std::max(nt, std::max(r.new_type_1, r.new_type_2) + 1); }
     for (auto& r : nb_rules) nt = std::max(nt, r.new_type + 1);
+    for (auto& c : atrp_centers) nt = std::max(nt, std::max(c.type, c.new_type) + 1);
     ntypes = nt;
     std::vector<PairCore<R>> hc((size_t)nt * nt);
     std::vector<PairExt<R>> he((size_t)nt * nt);
@@ -821,6 +831,7 @@ template <typename R> struct CtxT : Ctx {
     Trace trd("dd");
     const int nxy = box.nc[0] * box.nc[1];
     set_need_rebuild_async(1);
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&ctl.p->force_rebuild, 0, 1, stream));   // the request is being served (the force kernel's decision only reads it)
     // 1. bin the reals; leavers go to the migration buffers
     HIPCHK(hipMemsetAsync(mig[0].p, 0, 16, stream)); HIPCHK(hipMemsetAsync(mig[1].p, 0, 16, stream));
     launch_sort_chain(G, n);
@@ -925,13 +936,22 @@ template <typename R> struct CtxT : Ctx {
         const int old_cap = tile_cap;
         if (use_tiles && want > tile_cap) {
           tile_cap = want;
-          if (tile_lds_bytes() <= (size_t)150 * 1024) {
+          if (tile_lds_need() <= kTileLdsBudget) {
             set_tile_lds_attr(); setup_fused();
             set_ctl_field(&DevCtl::stage_overflow, 0);
             if (g_trace) fprintf(stderr, "[chem trace] staged-tile capacity %d -> %d slots\n", old_cap, tile_cap);
             continue;
           }
           tile_cap = old_cap;
+          if (!dd_on) {
+            // the stencil no longer fits the LDS next to the list build's image: this system continues on the per-cell
+            // kernels (int32 rows, positions through L1/L2) instead of failing
+            use_tiles = false; use_fused = false; ntiles = 0;
+            alloc_lists();
+            set_ctl_field(&DevCtl::stage_overflow, 0);
+            if (g_trace) fprintf(stderr, "[chem trace] stencil of %d particles does not fit the LDS: per-cell kernels\n", h.stage_overflow);
+            continue;
+          }
         }
         throw ChemError(CHEM_ENOSPC, "cell stencil holds " + std::to_string(h.stage_overflow) + " particles, LDS tile capacity " + std::to_string(use_tiles ? tile_cap : 1536) + " (local density too high for the LDS-staged tiles; set option tiles=0)");
       }
@@ -1027,7 +1047,7 @@ template <typename R> struct CtxT : Ctx {
 
   LangevinP<R> lang_params(int64_t istep, int phase) const {
     LangevinP<R> lp{};
-    lp.on = lang ? 1 : 0; lp.kT = kT; lp.gamma = gamma; lp.dt = dt; lp.seed = lang_seed; lp.step = (uint64_t)istep; lp.phase = (uint32_t)phase;
+    lp.on = lang ? 1 : 0; lp.kT = kT; lp.gamma = gamma; lp.dt = dt; lp.seed = lang_seed; lp.tmask = lang_tmask; lp.step = (uint64_t)istep; lp.phase = (uint32_t)phase;
     return lp;
   }
 
@@ -1186,16 +1206,18 @@ template <typename R> struct CtxT : Ctx {
       if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
       timed_step = opt_time_pair && (pair_launch_no++ % opt_time_pair) == 0;
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
+      const bool atrp_due = atrp_on && ((step + 1) % atrp.interval == 0);
       const bool last = (s == nsteps - 1);
       if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
       else { decide_and_rebuild(); compute_forces(); }
       resort = false;   // a rebuild requested by the last reaction step (force_rebuild on the device) has happened by now
 
-      if (last || react_due || !opt_fuse || resc_kind) {
+      if (last || react_due || atrp_due || !opt_fuse || resc_kind) {
         launch_integrate<1>(lang, lang, step, 1);
         ++step;
         if (resc_kind == 1 || resc_kind == 3 || (resc_kind == 2 && step % (int64_t)resc_param == 0)) rescale_velocities();
         if (react_due) react_step();
+        if (atrp_due) atrp_step();      // behind the reaction step: the driver adds the extension after `ar` (start_simulation.py:737-740)
         need_int1 = true;
       } else {
         tbeg(2);
@@ -1534,6 +1556,63 @@ template <typename R> struct CtxT : Ctx {
     }
     trc.lap("end");
     tm.reaction_wall_s += now_s() - t0;
+  }
+
+  // ---- ATRPActivator: every `interval` steps, on the host (a few thousand centres at reaction cadence) -----------
+  // Rule set: include/chem_mi355.h (chem_atrp_desc).  Types and states live on the device: the state array is read
+  // back, the type mirrors are replayed from the event arena, the flips go back through k_apply_props.
+  void atrp_step() {
+    HIPCHK(hipStreamSynchronize(stream));
+    join_async();
+    if (state_mirror_stale) { std::vector<int> hs; state.download(hs, nglob, stream); top.state.assign(hs.begin(), hs.end()); state_mirror_stale = false; }
+    struct Sel { uint32_t key; int32_t tag; uint32_t u; int center; };
+    auto center_of = [&](int32_t t) {
+      for (size_t c = 0; c < atrp_centers.size(); ++c) if (atrp_centers[c].type == top.type[t] && atrp_centers[c].state == top.state[t]) return (int)c;
+      return -1;
+    };
+    std::vector<Sel> pool;
+    int64_t ncand = 0;
+    for (int32_t t = 0; t < (int32_t)top.n; ++t) {
+      const int c = center_of(t);
+      if (c >= 0) ++ncand;
+      if (c < 0 && !atrp.select_from_all) continue;
+      uint32_t r[4];
+      chem_philox::atrp_draw(atrp.seed, (uint64_t)step, (uint32_t)t, r);
+      pool.push_back(Sel{r[0], t, r[1], c});
+    }
+    auto less = [](const Sel& a, const Sel& b) { return a.key != b.key ? a.key < b.key : a.tag < b.tag; };
+    if ((int64_t)pool.size() > atrp.num_particles) { std::nth_element(pool.begin(), pool.begin() + atrp.num_particles, pool.end(), less); pool.resize((size_t)atrp.num_particles); }
+    std::sort(pool.begin(), pool.end(), less);
+    const double dc = atrp.delta_catalyst / (double)atrp.num_particles;
+    chem_atrp_stats st{}; st.step = step; st.candidates = ncand; st.selected = (int64_t)pool.size();
+    std::vector<PropChangeDev> chg;
+    bool types_changed = false;
+    for (auto& sl : pool) {
+      if (sl.center < 0) continue;
+      const AtrpCenter& c = atrp_centers[sl.center];
+      const double p = c.is_activator ? atrp.k_deactivate * atrp.ratio_deactivator : atrp.k_activate * atrp.ratio_activator;
+      if (!(chem_philox::u01(sl.u) < p)) continue;
+      const int32_t t = sl.tag;
+      if (c.new_type >= 0 && c.new_type != top.type[t]) { top.type[t] = c.new_type; top.mass[t] = c.new_mass; top.q[t] = c.new_q; types_changed = true; }
+      top.state[t] += c.delta_state;
+      chg.push_back(PropChangeDev{t, top.type[t], 1, top.state[t], top.mass[t], top.q[t]});
+      if (c.is_activator) { const double m = std::min(dc, atrp.ratio_deactivator); atrp.ratio_deactivator -= m; atrp.ratio_activator += m; st.deactivated++; }
+      else { const double m = std::min(dc, atrp.ratio_activator); atrp.ratio_activator -= m; atrp.ratio_deactivator += m; st.activated++; }
+    }
+    st.ratio_activator = atrp.ratio_activator; st.ratio_deactivator = atrp.ratio_deactivator;
+    atrp_stats.push_back(st);
+    if (chg.empty()) return;
+    DBuf<PropChangeDev> dchg; dchg.alloc(chg.size());
+    HIPCHK(hipMemcpyAsync(dchg.p, chg.data(), chg.size() * sizeof(PropChangeDev), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL((k_apply_props<R>), dim3(cdiv((long long)chg.size(), 256)), dim3(256), 0, stream, (int)chg.size(), dchg.p, state.p, rtag.p, x4.p, v4.p);
+    HIPCHK(hipStreamSynchronize(stream));
+    if (types_changed) {     // the force list and the typed bonded slots depend on the types
+      bool any_typed = false;
+      for (auto& l : top.lists) any_typed |= l.by_types != 0;
+      if (any_typed) upload_bonded(false);
+      resort = true;
+      set_ctl_field(&DevCtl::force_rebuild, 1);
+    }
   }
 
   // ---- read-back ------------------------------------------------------------------------
@@ -1985,6 +2064,16 @@ int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t se
   API_END(ctx)
 }
 
+int chem_thermostat_langevin_types(chem_ctx* ctx, int n, const int32_t* types) {
+  API_BEGIN
+  REQUIRE(n >= 0 && (n == 0 || types), CHEM_EINVAL, "thermal groups");
+  uint32_t m = 0;
+  for (int k = 0; k < n; ++k) { REQUIRE(types[k] >= 0 && types[k] < CHEM_MAX_TYPES, CHEM_EINVAL, "thermal group type id"); m |= 1u << types[k]; }
+  CTX.lang_tmask = m;
+  return 0;
+  API_END(ctx)
+}
+
 int chem_thermostat_rescale(chem_ctx* ctx, int kind, double kT, double param) {
   API_BEGIN
   REQUIRE(kind >= 0 && kind <= 2, CHEM_EINVAL, "thermostat_rescale: kind must be 0 (off), 1 (Berendsen) or 2 (Isokinetic)");
@@ -2043,6 +2132,40 @@ int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* r) {
   REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "neighbour property changes on the decomposed path");
   c.nb_rules.push_back(*r); c.pair_dirty = true;
   return 0;
+  API_END(ctx)
+}
+
+int chem_atrp_init(chem_ctx* ctx, const chem_atrp_desc* d) {
+  API_BEGIN
+  Ctx& c = CTX;
+  if (!d) { c.atrp_on = false; return 0; }
+  REQUIRE(d->interval > 0 && d->num_particles > 0, CHEM_EINVAL, "atrp_init: interval and num_particles must be positive");
+  REQUIRE(d->ratio_activator >= 0 && d->ratio_deactivator >= 0 && d->delta_catalyst >= 0 && d->k_activate >= 0 && d->k_deactivate >= 0, CHEM_EINVAL, "atrp_init: negative rate or ratio");
+  REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "ATRPActivator on the decomposed path");
+  c.atrp = *d; c.atrp_on = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_atrp_add_center(chem_ctx* ctx, int type, int state, int is_activator, int new_type, double new_mass, double new_q, int delta_state) {
+  API_BEGIN
+  Ctx& c = CTX;
+  REQUIRE(type >= 0 && type < CHEM_MAX_TYPES && new_type < CHEM_MAX_TYPES, CHEM_EINVAL, "atrp_add_center: types");
+  REQUIRE(new_type < 0 || new_mass > 0, CHEM_EINVAL, "atrp_add_center: new_mass");
+  c.atrp_centers.push_back(Ctx::AtrpCenter{type, state, is_activator ? 1 : 0, new_type, delta_state, new_mass, new_q});
+  c.pair_dirty = true;    // (the type-pair tables must cover the new type)
+  return 0;
+  API_END(ctx)
+}
+
+int64_t chem_atrp_get_stats(chem_ctx* ctx, chem_atrp_stats* out, int64_t cap) {
+  API_BEGIN
+  Ctx& c = CTX;
+  const int64_t n = (int64_t)c.atrp_stats.size();
+  if (!out) return n;
+  REQUIRE(cap >= n, CHEM_ENOSPC, "atrp stats capacity");
+  std::copy(c.atrp_stats.begin(), c.atrp_stats.end(), out);
+  return n;
   API_END(ctx)
 }
 

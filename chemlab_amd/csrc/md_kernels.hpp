@@ -101,7 +101,8 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 // =======================================================================================
 // K7/K8  velocity-Verlet halves (start_simulation.py:165-167,780)
 // =======================================================================================
-template <typename R> struct LangevinP { int on; double kT, gamma, dt; uint64_t seed; uint64_t step; uint32_t phase; };
+template <typename R> struct LangevinP { int on; double kT, gamma, dt; uint64_t seed; uint64_t step; uint32_t phase;
+  uint32_t tmask; };   // thermal groups (LangevinThermostat.add_valid_types, start_simulation.py:312-336): bit t set = type t is thermalised; 0 = every type
 
 template <typename R>
 __device__ __forceinline__ void langevin_force(const LangevinP<R>& lp, int tag, R mass, R vx, R vy, R vz, R& fx, R& fy, R& fz) {
@@ -152,7 +153,12 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
       if (f2 > cap * cap) { const R s = cap / sqrt_r(f2); f.x *= s; f.y *= s; f.z *= s; }
     }
     if (LANG) {
-      langevin_force<R>(lp, tg[u], v.w, v.x, v.y, v.z, f.x, f.y, f.z);
+      bool on = true;
+      if (lp.tmask) {   // (uniform branch; the second half kick alone does not load the position: the type comes from x4 then)
+        const int ty = (int)((MODE & 2) ? xx[u].w : x4[i].w);
+        on = (lp.tmask >> (ty & 31)) & 1u;
+      }
+      if (on) langevin_force<R>(lp, tg[u], v.w, v.x, v.y, v.z, f.x, f.y, f.z);
       if (STOREF) f4[i] = f;
     }
     R hm = (R)0.5 * dt / v.w;
@@ -732,54 +738,63 @@ __global__ __launch_bounds__(256) void k_nlist_cells(int n, const Vec4<R>* __res
       int o = 0;
       for (int k = 0; k < 27; ++k) { seg_off[k] = o; o += seg_cnt[k]; }
       seg_off[27] = o;
-      if (o > CAP) atomicMax(&ctl->stage_overflow, o);
     }
     __syncthreads();
-    const int total = min(seg_off[27], CAP);
-    // stage: one wave per stencil cell round-robin, coalesced 16/32-byte loads
-    for (int k = w; k < 27; k += 4) {
-      const int s0 = seg_start[k], cnt = seg_cnt[k], o0 = seg_off[k];
-      const R sh0 = seg_shift[k][0], sh1 = seg_shift[k][1], sh2 = seg_shift[k][2];
-      for (int t = l; t < cnt; t += 64) {
-        const int dst = o0 + t;
-        if (dst < CAP) {
-          Vec4<R> p = x4[s0 + t];
-          p.x += sh0; p.y += sh1; p.z += sh2; p.w = idx_as_real(s0 + t, (R)0);
-          sx[dst] = p;
-        }
-      }
-    }
-    __syncthreads();
+    const int total_all = seg_off[27];
     const int hs = cell_start[c], he = cell_start[c + 1];
-    for (int p = hs + w; p < he; p += 4) {
-      const Vec4<R> xi = x4[p];
-      int e0 = 0, e1 = 0;
-      if (has_excl) { int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
-      int cnt = 0;
-      int* row = nlist + (size_t)p * S;
-      for (int s0 = 0; s0 < total; s0 += 64) {
-        const int s = s0 + l;
-        bool ok = s < total;
-        int j = -1;
-        if (ok) {
-          const Vec4<R> xj = sx[s];
-          j = real_as_idx(xj.w);
-          const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-          const R r2 = dx * dx + dy * dy + dz * dz;
-          ok = (r2 <= rl2) && (j != p);
-          if (ok && e1 > e0) {
-            const int tj = tag[j];
-            for (int e = e0; e < e1; ++e) if (excl_list[e] == tj) { ok = false; break; }
+    // A stencil that holds more than CAP particles (dense systems that have left the LDS tiles) is walked in windows of
+    // CAP slots; a home particle's running count waits in nn[] between two windows (written and read back by lane 0 of
+    // the wave that owns the particle).
+    for (int base = 0; base < total_all || base == 0; base += CAP) {
+      if (base) __syncthreads();
+      const int total = min(total_all - base, CAP);
+      // stage: one wave per stencil cell round-robin, coalesced 16/32-byte loads
+      for (int k = w; k < 27; k += 4) {
+        const int s0 = seg_start[k], cnt = seg_cnt[k], o0 = seg_off[k] - base;
+        const R sh0 = seg_shift[k][0], sh1 = seg_shift[k][1], sh2 = seg_shift[k][2];
+        for (int t = l; t < cnt; t += 64) {
+          const int dst = o0 + t;
+          if (dst >= 0 && dst < CAP) {
+            Vec4<R> p = x4[s0 + t];
+            p.x += sh0; p.y += sh1; p.z += sh2; p.w = idx_as_real(s0 + t, (R)0);
+            sx[dst] = p;
           }
         }
-        const unsigned long long m = __ballot(ok);
-        if (ok) {
-          const int pos = cnt + __popcll(m & lanemask_lt());
-          if (pos < S) row[pos] = j;
-        }
-        cnt += __popcll(m);
       }
-      finish_row(row, nn, p, cnt, S, l, ctl);
+      __syncthreads();
+      const bool last = base + CAP >= total_all;
+      for (int p = hs + w; p < he; p += 4) {
+        const Vec4<R> xi = x4[p];
+        int e0 = 0, e1 = 0;
+        if (has_excl) { int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
+        int cnt = 0;
+        if (base) { if (l == 0) cnt = nn[p]; cnt = __shfl(cnt, 0); }
+        int* row = nlist + (size_t)p * S;
+        for (int s0 = 0; s0 < total; s0 += 64) {
+          const int s = s0 + l;
+          bool ok = s < total;
+          int j = -1;
+          if (ok) {
+            const Vec4<R> xj = sx[s];
+            j = real_as_idx(xj.w);
+            const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+            const R r2 = dx * dx + dy * dy + dz * dz;
+            ok = (r2 <= rl2) && (j != p);
+            if (ok && e1 > e0) {
+              const int tj = tag[j];
+              for (int e = e0; e < e1; ++e) if (excl_list[e] == tj) { ok = false; break; }
+            }
+          }
+          const unsigned long long m = __ballot(ok);
+          if (ok) {
+            const int pos = cnt + __popcll(m & lanemask_lt());
+            if (pos < S) row[pos] = j;
+          }
+          cnt += __popcll(m);
+        }
+        if (last) finish_row(row, nn, p, cnt, S, l, ctl);
+        else if (l == 0) nn[p] = cnt;
+      }
     }
   }
 }
@@ -927,7 +942,16 @@ __global__ __launch_bounds__(256) void k_pair_force(int n, const Vec4<R>* __rest
 // The staged order is a pure function of cell_start, which only changes at a rebuild, so the
 // build kernel and every later force launch see the same slot numbering.
 // =======================================================================================
-constexpr int HX = 3, HY = 3, HZ = 3;   // ~490 home particles at 18/cell: one pass of a 512-thread block; stencil 5^3 cells (x4.6)
+#ifndef CHEM_HX
+#define CHEM_HX 3
+#endif
+#ifndef CHEM_HY
+#define CHEM_HY 3
+#endif
+#ifndef CHEM_HZ
+#define CHEM_HZ 3
+#endif
+constexpr int HX = CHEM_HX, HY = CHEM_HY, HZ = CHEM_HZ;   // ~490 home particles at 18/cell: one pass of a 512-thread block; stencil 5^3 cells (x4.6)
 constexpr int SX = HX + 2, SY = HY + 2, SZ = HZ + 2;
 constexpr int NROW = SY * SZ;          // x-rows of the stencil
 constexpr int NHSEG = HY * HZ;         // home x-runs (contiguous in memory)
@@ -1760,7 +1784,9 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
     const int need = (acc > half_skin) || ctl->force_rebuild;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       ctl->step_m2 = m2; ctl->acc_pp[da.par ^ 1] = need ? 0.0 : acc; ctl->acc_maxdist = need ? 0.0 : acc;
-      if (need) { ctl->force_rebuild = 0; ctl->rebuild_count++; }
+      // (force_rebuild is NOT cleared here: workgroups that start later must read the same value -- the host clears it,
+      //  stream-ordered, at the top of the slab rebuild this decision triggers)
+      if (need) ctl->rebuild_count++;
       ctl->need_rebuild = need;
       da.host_flag[0] = need;
       __threadfence_system();

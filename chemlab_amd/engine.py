@@ -129,6 +129,11 @@ class Engine:
     def thermostat_langevin(self, kT, gamma, seed=0):
         self._ck(self.api.thermostat_langevin(self.ctx, float(kT), float(gamma), int(seed)))
 
+    def thermostat_langevin_types(self, types):
+        """Thermal groups (LangevinThermostat.add_valid_types): thermalise only these particle types; [] = all."""
+        t = np.ascontiguousarray(list(types), dtype=np.int32)
+        self._ck(self.api.thermostat_langevin_types(self.ctx, t.shape[0], _ptr(t, C.c_int32)))
+
     def table_create(self, r0, dr, e, f):
         """Bond table (rows of a .pot file); returns the handle to pass as list_set_params(h, [handle])."""
         e = np.ascontiguousarray(e, dtype=np.float64); f = np.ascontiguousarray(f, dtype=np.float64)
@@ -167,6 +172,26 @@ class Engine:
         r = _capi.NbChange(int(reaction), io, int(old_type), int(nb_level), int(new_type), 0 if new_state is None else 1,
                            0 if new_state is None else int(new_state), 0, float(new_mass), float(new_q))
         self._ck(self.api.reaction_neighbour_change(self.ctx, C.byref(r)))
+
+    def atrp_init(self, interval, num_particles, ratio_activator, ratio_deactivator, delta_catalyst, k_activate, k_deactivate,
+                  select_from_all=True, seed=0):
+        """integrator.ATRPActivator(system, interval, num_particles, ...) (reaction_post_process.py:380-426)."""
+        d = _capi.AtrpDesc(int(interval), int(num_particles), 1 if select_from_all else 0, 0, float(ratio_activator), float(ratio_deactivator),
+                           float(delta_catalyst), float(k_activate), float(k_deactivate), int(seed))
+        self._ck(self.api.atrp_init(self.ctx, C.byref(d)))
+
+    def atrp_disconnect(self):
+        self._ck(self.api.atrp_init(self.ctx, None))
+
+    def atrp_add_center(self, type_id, state, is_activator, new_type, new_mass, new_q=0.0, delta_state=0):
+        self._ck(self.api.atrp_add_center(self.ctx, int(type_id), int(state), 1 if is_activator else 0, int(new_type), float(new_mass), float(new_q), int(delta_state)))
+
+    def atrp_stats(self):
+        n = self._ck(self.api.atrp_get_stats(self.ctx, None, 0))
+        buf = (_capi.AtrpStats * max(n, 1))()
+        if n:
+            self._ck(self.api.atrp_get_stats(self.ctx, buf, n))
+        return [{k: getattr(buf[i], k) for k, _ in _capi.AtrpStats._fields_} for i in range(n)]
 
     def topology_register(self, h, types):
         t = np.ascontiguousarray(types, dtype=np.int32)

@@ -602,11 +602,17 @@ class _LangevinThermostat(object):
         self.valid_types = None
 
     def add_valid_types(self, types_):
-        raise NotImplementedError("LangevinThermostat.add_valid_types (thermal groups) is outside the hot-path scope")
+        """Thermal groups (start_simulation.py:312-336): only particles whose current type is listed are thermalised;
+        an empty list (no --thermal_groups / --table_groups) leaves every type thermalised."""
+        self.valid_types = sorted(set(int(t) for t in types_ if t is not None))
+        if getattr(self, "_connected", False):
+            self.system.engine.thermostat_langevin_types(self.valid_types)
 
     def _connect(self, integrator):
         seed = self.system.rng.get_seed() if self.system.rng is not None else 0
         self.system.engine.thermostat_langevin(self.temperature, self.gamma, seed)
+        self.system.engine.thermostat_langevin_types(self.valid_types or [])
+        self._connected = True
 
 
 class _BerendsenThermostat(object):
@@ -671,6 +677,53 @@ class _CapForce(object):
 class _TopologyParticleProperties(object):
     def __init__(self, type=None, mass=None, q=None, state=None, **kw):
         self.type, self.mass, self.q, self.state = type, mass, q, state
+
+
+class _ATRPActivator(object):
+    """integrator.ATRPActivator(system, interval, num_particles, ratio_activator, ratio_deactivator, delta_catalyst,
+    k_activate, k_deactivate): .stats_filename, .select_from_all, add_reactive_center(type_id, state, is_activator,
+    new_property, delta_state) (reaction_post_process.py:380-426).  Bound to chem_atrp_* when added to the integrator."""
+
+    def __init__(self, system, interval, num_particles, ratio_activator, ratio_deactivator, delta_catalyst, k_activate, k_deactivate):
+        self.system = system
+        self.interval, self.num_particles = int(interval), int(num_particles)
+        self.ratio_activator, self.ratio_deactivator = float(ratio_activator), float(ratio_deactivator)
+        self.delta_catalyst, self.k_activate, self.k_deactivate = float(delta_catalyst), float(k_activate), float(k_deactivate)
+        self.stats_filename = None
+        self.select_from_all = 1
+        self._centers = []
+        self._connected = False
+
+    def add_reactive_center(self, type_id, state, is_activator, new_property, delta_state):
+        c = (int(type_id), int(state), bool(is_activator), int(new_property.type), float(new_property.mass), float(new_property.q or 0.0), int(delta_state))
+        self._centers.append(c)
+        if self._connected:
+            self.system.engine.atrp_add_center(*c)
+
+    def _connect(self, integrator):
+        e = self.system.engine
+        seed = self.system.rng.get_seed() if self.system.rng is not None else 0
+        if not self._connected:
+            for c in self._centers:
+                e.atrp_add_center(*c)
+        e.atrp_init(self.interval, self.num_particles, self.ratio_activator, self.ratio_deactivator, self.delta_catalyst,
+                    self.k_activate, self.k_deactivate, select_from_all=bool(int(self.select_from_all)), seed=seed)
+        self._connected = True
+
+    def disconnect(self):
+        self.system.engine.atrp_disconnect()
+
+    def save_stats(self, filename=None):
+        """One row per firing: step, activator and deactivator fractions, flips (the reference's `stats_file`)."""
+        filename = filename or self.stats_filename
+        rows = self.system.engine.atrp_stats()
+        if filename:
+            with open(filename, "w") as f:
+                f.write("# step ratio_activator ratio_deactivator activated deactivated candidates selected\n")
+                for r in rows:
+                    f.write("%d %.10g %.10g %d %d %d %d\n" % (r["step"], r["ratio_activator"], r["ratio_deactivator"], r["activated"],
+                                                              r["deactivated"], r["candidates"], r["selected"]))
+        return rows
 
 
 class _PostProcessChangeNeighboursProperty(object):
@@ -903,7 +956,7 @@ integrator = _ns(
     BerendsenThermostat=_BerendsenThermostat, BerendsenBarostat=_unsupported("integrator.BerendsenBarostat"),
     Isokinetic=_Isokinetic, LangevinBarostat=_unsupported("integrator.LangevinBarostat"),
     CapForce=_CapForce, RestrictReaction=_unsupported("integrator.RestrictReaction"),
-    DissociationReaction=_unsupported("integrator.DissociationReaction"), ATRPActivator=_unsupported("integrator.ATRPActivator"),
+    DissociationReaction=_unsupported("integrator.DissociationReaction"), ATRPActivator=_ATRPActivator,
     ReactionCutoffRandom=_unsupported("integrator.ReactionCutoffRandom"), FixDistances=_unsupported("integrator.FixDistances"),
     ChangeInRegion=_unsupported("integrator.ChangeInRegion"), BasicDynamicResolution=_unsupported("integrator.BasicDynamicResolution"),
     PostProcessChangeNeighboursProperty=_PostProcessChangeNeighboursProperty,

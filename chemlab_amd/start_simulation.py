@@ -193,12 +193,13 @@ def main(argv=None, hooks=None, quiet=False):
     if file_hooks:
         log("Found hooks.py")
     hooks = dict(file_hooks, **(hooks or {}))
-    ar, chem_fpls, cr_interval, dynamic_types = None, [], None, set()
+    ar, chem_fpls, cr_interval, dynamic_types, integrator_extensions = None, [], None, set(), []
     reaction_index = {}
     if args.reactions is not None and os.path.exists(args.reactions):
         rc = reaction_parser.parse_config(args.reactions)
         sc = reaction_setup.SetupReactions(espressopp, system, verletlist, gt, topology_manager, rc, args)
         ar, chem_fpls = sc.setup_reactions()
+        integrator_extensions = sc.extensions_to_integrator
         dynamic_types = sc.dynamic_types
         reaction_index = {k: cr["equation"] for k, cr in enumerate(c for g in rc["reactions"].values() for c in g["reaction_list"])}
         system.engine.set_option("count_intra_inter", 1)   # ar.save_intra_inter_counter at the end of the run
@@ -286,6 +287,8 @@ def main(argv=None, hooks=None, quiet=False):
         if cad["k_enable_reactions"] == k and ar is not None:
             log("Enabling chemical reactions")
             integrator.addExtension(ar)
+            for ext in integrator_extensions:                # start_simulation.py:738-740 (ATRPActivator)
+                integrator.addExtension(ext)
             reactions_enabled = True
             pos, vel = _conf_positions(system, conf, unfolded=True)      # start_simulation.py:741-745
             outputs.write_gro("%s_%s_before_reaction_confout.gro" % (args.output_prefix, args.rng_seed), conf, pos, conf.box, velocities=vel)
@@ -314,6 +317,9 @@ def main(argv=None, hooks=None, quiet=False):
         hooks["hook_end"](system, integrator, ar, gt, args)
     mon.info() if not quiet else None
     write_final_outputs(args, system, gt, conf, bonded, angles, dihedrals, chem_fpls, topology_manager, ar, reaction_index)
+    for ext in integrator_extensions:
+        if hasattr(ext, "save_stats"):
+            ext.save_stats()                                  # ATRPActivator.stats_filename (reaction_post_process.py:390-396)
     npart = espressopp.analysis.NPart(system).compute()
     with open("%s_%s_benchmark.csv" % (args.output_prefix, rng_seed), "a+") as f:
         f.write("%d %d %s %s\n" % (1, npart, total_time, integrator_loop))

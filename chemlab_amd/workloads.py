@@ -228,6 +228,8 @@ def apply(spec, eng, thermostat=True, reactions=True):
         eng.set_exclusions(spec["exclusions"])
     if thermostat and spec.get("gamma", 0) > 0:
         eng.thermostat_langevin(spec["kT"], spec["gamma"], spec["seed"])
+        if spec.get("thermal_types") is not None:       # thermal groups (start_simulation.py:312-336)
+            eng.thermostat_langevin_types(spec["thermal_types"])
     rx = spec.get("reaction")
     if rx and reactions:
         hb = eng.list_create(2, rx["bond"][0], False)
@@ -242,4 +244,10 @@ def apply(spec, eng, thermostat=True, reactions=True):
                     r["new_mass_%d" % k] = rx["type_mass"][nt]
             eng.reaction_add(bond_list=hb, **r)
         eng.reactions_enable(True)
+    at = spec.get("atrp")
+    if at and reactions:        # ATRPActivator (reaction_post_process.py:380-426), added behind the reactions
+        for c in at["centers"]:
+            eng.atrp_add_center(**c)
+        eng.atrp_init(at["interval"], at["num_particles"], at["ratio_activator"], at["ratio_deactivator"], at["delta_catalyst"],
+                      at["k_activate"], at["k_deactivate"], select_from_all=at.get("select_from_all", True), seed=at.get("seed", spec.get("seed", 0)))
     return handles

@@ -218,6 +218,10 @@ int64_t chem_get_list(chem_ctx* ctx, int list, int64_t* out, int64_t cap_entries
 /* integrator.LangevinThermostat: .temperature (=T*kb), .gamma  start_simulation.py:330-336.
  * gamma<=0 or kT<0 switches it off (thermostat=no, Q6 in SURVEY). */
 int chem_thermostat_langevin(chem_ctx* ctx, double kT, double gamma, uint64_t seed);
+/* LangevinThermostat.add_valid_types(thermal_groups)  start_simulation.py:312-336: friction and noise act only on
+ * particles whose CURRENT type is listed (types change through reactions); n = 0 restores "every type" (the
+ * reference passes an empty list when neither --thermal_groups nor --table_groups is given). */
+int chem_thermostat_langevin_types(chem_ctx* ctx, int n, const int32_t* types);
 /* integrator.BerendsenThermostat(system) (.temperature, .tau) and integrator.Isokinetic(system) (.temperature,
  * .coupling) -- start_simulation.py:341-348 (`thermostat = br | iso`): velocity rescaling after the second half
  * kick of a step (aftIntV).  With kT_now = 2 Ekin / (3 N):
@@ -259,6 +263,33 @@ typedef struct chem_nb_change {
   double  new_mass, new_q;
 } chem_nb_change;
 int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* rule);
+/* integrator.ATRPActivator(system, interval, num_particles, ratio_activator, ratio_deactivator, delta_catalyst,
+ *     k_activate, k_deactivate) + .select_from_all + add_reactive_center(type_id, state, is_activator, new_property,
+ *     delta_state)  -- src/chemlab/reaction_post_process.py:380-426, examples/atrp_lj/atrp.cfg:15-25.  An integrator
+ * extension that fires every `interval` steps (after the reaction step when both fall on the same step -- the driver
+ * adds it behind `ar`, start_simulation.py:737-740) and flips reactive centres between dormant and active:
+ *   pool      = every particle (select_from_all != 0) or every particle matching a centre's (type, state);
+ *   selection = the num_particles members of the pool with the smallest key (Philox stream keyed (seed, step, tag):
+ *               out[0] = key, ties by tag; out[1] = acceptance uniform); visited in that order;
+ *   a selected particle matching centre c (first match in insertion order) is flipped with probability
+ *               k_activate * ratio_activator   when c.is_activator == 0  ("A" centres: consume activator),
+ *               k_deactivate * ratio_deactivator when c.is_activator != 0 ("DA" centres: consume deactivator);
+ *   a flip sets type/mass/q to the centre's new property, state += delta_state, and moves
+ *               delta_catalyst / num_particles of catalyst from the consumed pool to the other one (clamped at 0).
+ * The arithmetic lives in the external ESPResSo++ fork; this rule set is this build's restatement of the call
+ * site's contract ([EXT-RECALL]).  desc == NULL disconnects the extension. */
+typedef struct chem_atrp_desc {
+  int32_t interval, num_particles, select_from_all, pad;
+  double  ratio_activator, ratio_deactivator, delta_catalyst, k_activate, k_deactivate;
+  uint64_t seed;
+} chem_atrp_desc;
+typedef struct chem_atrp_stats {     /* one row per firing (the reference writes them to `stats_file`) */
+  int64_t step, candidates, selected, activated, deactivated;
+  double  ratio_activator, ratio_deactivator;
+} chem_atrp_stats;
+int chem_atrp_init(chem_ctx* ctx, const chem_atrp_desc* desc);
+int chem_atrp_add_center(chem_ctx* ctx, int type, int state, int is_activator, int new_type, double new_mass, double new_q, int delta_state);
+int64_t chem_atrp_get_stats(chem_ctx* ctx, chem_atrp_stats* out, int64_t cap);
 /* integrator.addExtension(ar) / ar.disconnect()  start_simulation.py:735-741,776-777 */
 int chem_reactions_enable(chem_ctx* ctx, int on);
 /* per-reaction rate update (Arrhenius hook, start_simulation.py:785-796) */

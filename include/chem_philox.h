@@ -63,6 +63,13 @@ CHEM_HD void reaction_draw(uint64_t seed, uint64_t step, uint32_t tag_lo, uint32
   philox4x32_10(ctr, key, out);
 }
 
+/* ATRPActivator (chem_atrp_init): selection key out[0] and acceptance uniform out[1] of particle `tag` at step `step`. */
+CHEM_HD void atrp_draw(uint64_t seed, uint64_t step, uint32_t tag, uint32_t out[4]) {
+  uint32_t ctr[4] = {tag, (uint32_t)step, (uint32_t)(step >> 32), 0x41545250u};
+  uint32_t key[2] = {(uint32_t)seed ^ 0x41435456u, (uint32_t)(seed >> 32)};
+  philox4x32_10(ctr, key, out);
+}
+
 /* ---- StochasticVelocityRescaling (Bussi, Donadio, Parrinello, J. Chem. Phys. 126, 014101 (2007)) ----
  * One scalar per step: the new kinetic energy drawn from the canonical distribution relaxing with time
  * constant taut (in steps).  The stream is keyed (seed, step); oracle and device run this same code on

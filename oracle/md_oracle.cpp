@@ -104,12 +104,15 @@ struct Orc {
   PairPot pp[CHEM_MAX_TYPES][CHEM_MAX_TYPES];
   std::vector<BondedList> lists;
   // thermostat
-  bool lang = false; double kT = 0, gamma = 0; uint64_t lang_seed = 0;
+  bool lang = false; double kT = 0, gamma = 0; uint64_t lang_seed = 0; uint32_t lang_tmask = 0;   // thermal groups: start_simulation.py:312-336
   // reactions
   bool react_init = false, react_on = false;
   int interval = 0, nearest = 1, max_per_interval = 0; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
   std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty
+  // integrator.ATRPActivator (reaction_post_process.py:380-426)
+  struct AtrpCenter { int type, state, is_activator, new_type, delta_state; double new_mass, new_q; };
+  bool atrp_on = false; chem_atrp_desc atrp{}; std::vector<AtrpCenter> atrp_centers; std::vector<chem_atrp_stats> atrp_stats;
   std::vector<chem_event> events;
   // integrator state
   int64_t step = 0;
@@ -511,6 +514,7 @@ static void update_forces(Orc& o, int64_t istep, int phase) {
   if (o.lang) {
 #pragma omp parallel for schedule(static) num_threads(o.threads) if (o.threads > 1)
     for (int64_t i = 0; i < o.n; ++i) {
+      if (o.lang_tmask && !((o.lang_tmask >> (o.type[i] & 31)) & 1u)) continue;   // add_valid_types: only the listed (current) types
       uint32_t r[4];
       chem_philox::langevin_draw(o.lang_seed, (uint64_t)istep, (uint32_t)phase, (uint32_t)i, r);
       double m = o.mass[i], pref = std::sqrt(24.0 * o.kT * o.gamma * m / o.dt);
@@ -692,6 +696,44 @@ static void react(Orc& o) {
   }
 }
 
+// ---- ATRPActivator (reaction_post_process.py:380-426; rule set in include/chem_mi355.h) ----
+static void atrp_step(Orc& o) {
+  struct Sel { uint32_t key; int32_t tag; uint32_t u; int center; };
+  auto center_of = [&](int32_t t) {
+    for (size_t c = 0; c < o.atrp_centers.size(); ++c) if (o.atrp_centers[c].type == o.type[t] && o.atrp_centers[c].state == o.state[t]) return (int)c;
+    return -1;
+  };
+  std::vector<Sel> pool;
+  int64_t ncand = 0;
+  for (int32_t t = 0; t < (int32_t)o.n; ++t) {
+    const int c = center_of(t);
+    if (c >= 0) ++ncand;
+    if (c < 0 && !o.atrp.select_from_all) continue;
+    uint32_t r[4];
+    chem_philox::atrp_draw(o.atrp.seed, (uint64_t)o.step, (uint32_t)t, r);
+    pool.push_back({r[0], t, r[1], c});
+  }
+  std::sort(pool.begin(), pool.end(), [](const Sel& a, const Sel& b) { return std::make_pair(a.key, a.tag) < std::make_pair(b.key, b.tag); });
+  if ((int64_t)pool.size() > o.atrp.num_particles) pool.resize((size_t)o.atrp.num_particles);
+  const double dc = o.atrp.delta_catalyst / (double)o.atrp.num_particles;
+  chem_atrp_stats st{}; st.step = o.step; st.candidates = ncand; st.selected = (int64_t)pool.size();
+  bool changed = false;
+  for (auto& s : pool) {
+    if (s.center < 0) continue;
+    const Orc::AtrpCenter& c = o.atrp_centers[s.center];
+    const double p = c.is_activator ? o.atrp.k_deactivate * o.atrp.ratio_deactivator : o.atrp.k_activate * o.atrp.ratio_activator;
+    if (!(chem_philox::u01(s.u) < p)) continue;
+    if (c.new_type >= 0 && c.new_type != o.type[s.tag]) { o.type[s.tag] = c.new_type; o.mass[s.tag] = c.new_mass; o.q[s.tag] = c.new_q; }
+    o.state[s.tag] += c.delta_state;
+    if (c.is_activator) { const double m = std::min(dc, o.atrp.ratio_deactivator); o.atrp.ratio_deactivator -= m; o.atrp.ratio_activator += m; st.deactivated++; }
+    else { const double m = std::min(dc, o.atrp.ratio_activator); o.atrp.ratio_activator -= m; o.atrp.ratio_deactivator += m; st.activated++; }
+    changed = true;
+  }
+  st.ratio_activator = o.atrp.ratio_activator; st.ratio_deactivator = o.atrp.ratio_deactivator;
+  o.atrp_stats.push_back(st);
+  if (changed) o.resort = true;
+}
+
 // ---- integrator ---------------------------------------------------------------------
 
 static void run(Orc& o, int64_t nsteps) {
@@ -726,6 +768,7 @@ static void run(Orc& o, int64_t nsteps) {
       for (int64_t i = 0; i < o.n; ++i) o.v[i] = lam * o.v[i];
     }
     if (o.react_on && o.interval > 0 && o.step % o.interval == 0) react(o);
+    if (o.atrp_on && o.step % o.atrp.interval == 0) atrp_step(o);   // added to the integrator behind `ar` (start_simulation.py:737-740)
   }
 }
 
@@ -877,6 +920,12 @@ int orc_thermostat_langevin(void* c, double kT, double gamma, uint64_t seed) {
   Orc& o = O(c); o.lang = (gamma > 0 && kT >= 0); o.kT = kT; o.gamma = gamma; o.lang_seed = seed; return 0;
 }
 
+int orc_thermostat_langevin_types(void* c, int n, const int32_t* types) {
+  Orc& o = O(c); uint32_t m = 0;
+  for (int k = 0; k < n; ++k) { if (types[k] < 0 || types[k] >= CHEM_MAX_TYPES) FAIL(CHEM_EINVAL, "thermal group type id"); m |= 1u << types[k]; }
+  o.lang_tmask = m; return 0;
+}
+
 int orc_reaction_init(void* c, int interval, int nearest, int max_per_interval, uint64_t seed) {
   Orc& o = O(c); if (interval <= 0) FAIL(CHEM_EINVAL, "interval");
   o.react_init = true; o.interval = interval; o.nearest = nearest; o.max_per_interval = max_per_interval; o.react_seed = seed; return 0;
@@ -895,6 +944,23 @@ int orc_reaction_neighbour_change(void* c, const chem_nb_change* r) {
       r->old_type < 0 || r->old_type >= CHEM_MAX_TYPES || r->new_type < 0 || r->new_type >= CHEM_MAX_TYPES || !(r->new_mass > 0))
     FAIL(CHEM_EINVAL, "reaction_neighbour_change");
   o.nb_rules.push_back(*r); return 0;
+}
+
+int orc_atrp_init(void* c, const chem_atrp_desc* d) {
+  Orc& o = O(c);
+  if (!d) { o.atrp_on = false; return 0; }
+  if (d->interval <= 0 || d->num_particles <= 0) FAIL(CHEM_EINVAL, "atrp_init");
+  o.atrp = *d; o.atrp_on = true; return 0;
+}
+int orc_atrp_add_center(void* c, int type, int state, int is_activator, int new_type, double new_mass, double new_q, int delta_state) {
+  Orc& o = O(c);
+  if (type < 0 || type >= CHEM_MAX_TYPES || new_type >= CHEM_MAX_TYPES) FAIL(CHEM_EINVAL, "atrp_add_center");
+  o.atrp_centers.push_back({type, state, is_activator, new_type, delta_state, new_mass, new_q}); return 0;
+}
+int64_t orc_atrp_get_stats(void* c, chem_atrp_stats* out, int64_t cap) {
+  Orc& o = O(c); const int64_t n = (int64_t)o.atrp_stats.size();
+  if (!out) return n; if (cap < n) FAIL(CHEM_ENOSPC, "atrp stats cap");
+  std::copy(o.atrp_stats.begin(), o.atrp_stats.end(), out); return n;
 }
 
 int orc_topology_register(void* c, int arity, int list, const int32_t* types) {

@@ -40,6 +40,27 @@ LIB_OMP = os.path.join(HERE, "liboracle_omp.so")
 _api_omp = None
 
 
+def lscpu_cores():
+    """(logical CPUs, physical cores) of the host as `lscpu` reports them (the core count goes into the log next to
+    the CPU baseline); None where lscpu is missing."""
+    import subprocess
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+    except Exception:
+        return None
+    kv = {}
+    for line in txt.splitlines():
+        if ":" in line:
+            k, v = line.split(":", 1)
+            kv[k.strip()] = v.strip()
+    try:
+        logical = int(kv["CPU(s)"])
+        phys = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+        return logical, phys
+    except Exception:
+        return None
+
+
 def host_cores():
     """Cores this process may actually use: the affinity mask (what `nproc` prints) capped by the cgroup CPU
     quota when one is set (a GPU box shows every core of the host but grants a share of them)."""

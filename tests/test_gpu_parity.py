@@ -970,8 +970,13 @@ def test_bench_multi_process_over_ipc_on_one_gpu(tmp_path, nranks):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", CHEM_TRANSPORT="ipc")
     common = ["--steps", "40", "--warmup", "10", "--particles", "64000", "--interval", "20", "--equil", "100", "--cpu-steps", "0", "--f64-steps", "0"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nranks)] + common
+    if nranks == 2:
+        # the way the driver starts it: plainly -- bench.py spawns the ranks itself (a child torch.distributed.run)
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(nranks)] + common
+        env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nranks)] + common
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-3000:])
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]

@@ -66,3 +66,21 @@ def test_two_rank_gloo_rendezvous_and_partition(tmp_path):
     import json
     out = [json.load(open(tmp_path / ("rank_%d.json" % r))) for r in range(2)]
     assert [o["rank"] for o in out] == [0, 1]
+
+
+def test_bench_started_plainly_spawns_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` (the driver's command line, no torch.distributed.run around it): the parent starts the
+    ranks as a child process and relays rank 0's line and the exit code.  --rendezvous-only stops before any GPU work."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert d == dict(rendezvous="ok", n_gpus=2, max_rank=1, node_grid=list(multigpu.node_grid(2)))
+    # a failing rank's exit code comes back through the parent (no GPU here: chem_create fails loudly)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--particles", "8788", "--equil", "0", "--steps", "1",
+                          "--warmup", "0", "--cpu-steps", "0", "--f64-steps", "0"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    import torch
+    if not torch.cuda.is_available():
+        assert bad.returncode != 0
