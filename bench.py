@@ -15,6 +15,7 @@ Sequence (all set-up outside the timer):
   2. reactions enabled, W warm-up steps, then EXACTLY K timed steps;
   3. if no reaction step fell into the timed region (K < interval), the next reaction step is timed
      on its own afterwards and reported as `reaction_step_ms` (it is never folded into `value`);
+  3b. `late_stage`: 10 more reaction steps (untimed), then max(K, 400) timed steps of the gelled system;
   4. an fp64 run of the same melted state (`f64` object: the reference computes in fp64);
   5. the CPU restatement on the same melted state, one core and all cores (`cpu_baseline`).
 """
@@ -40,6 +41,7 @@ def parse():
     # (`--particles`, not `--n`: torch.distributed.run's own parser claims every `--n...` prefix as ambiguous)
     p.add_argument("--particles", "--n", dest="n", type=int, default=1000000, help="particles (C5: 1,000,000 = 100^3 sc lattice)")
     p.add_argument("--rho", type=float, default=0.8)
+    p.add_argument("--skin", type=float, default=0.3, help="Verlet skin of the workload (BASELINE C5: 0.3)")
     p.add_argument("--interval", type=int, default=500)
     p.add_argument("--equil", type=int, default=2000, help="untimed melting steps before reactions are enabled")
     p.add_argument("--precision", type=int, default=32)
@@ -48,13 +50,14 @@ def parse():
     p.add_argument("--tpp", type=int, default=0)
     p.add_argument("--opt", action="append", default=[], help="name=value engine option (tuning)")
     p.add_argument("--no-roofline", action="store_true")
+    p.add_argument("--late-stage", type=int, default=10, help="reaction steps to advance (untimed) before the late-stage leg (0 = skip)")
     p.add_argument("--verbose", action="store_true", help="timers to stderr")
     p.add_argument("--rendezvous-only", action="store_true",
                    help="N > 1: start the ranks, run the gloo rendezvous (barrier + max over ranks) and stop before any GPU work")
     return p.parse_args()
 
 
-WORKLOAD = ("C5 reactive LJ melt (chain_growth_catalytic shape): %d particles, rho*=%.4g, rc=2.5, skin=0.3, dt=0.005, "
+WORKLOAD = ("C5 reactive LJ melt (chain_growth_catalytic shape): %d particles, rho*=%.4g, rc=2.5, skin=%.3g, dt=0.005, "
             "Langevin gamma=5 T=0.5, 4 reactions every %d steps; melted for %d steps before the reactions start")
 
 
@@ -189,7 +192,9 @@ def run_leg(a, spec, precision, local_rank, equil_state=None, steps=None, warmup
     tm0 = eng.timers()
     if not a.no_roofline:
         # HIP events on the launch stream around the per-step kernels of every N-th step of the TIMED region
-        eng.set_option("time_pair_kernel", max(1, steps // 256))
+        # (every 5th step at least: the event records between the launches cost ~25 us on a sampled step -- with every step
+        #  of a 20-step region sampled, `value` came out 18 % low)
+        eng.set_option("time_pair_kernel", max(5, steps // 256))
     t0 = time.perf_counter()
     eng.run(steps)
     eng.sync()
@@ -197,7 +202,8 @@ def run_leg(a, spec, precision, local_rank, equil_state=None, steps=None, warmup
     tm = eng.timers()
     eng.set_option("time_pair_kernel", 0)
     info.update(wall=wall, tm=tm, events=len(eng.get_events()) - ev0, reaction_steps_timed=tm["reaction_steps"] - tm0["reaction_steps"],
-                rebuilds_timed=tm["rebuilds"] - tm0["rebuilds"], reaction_wall_s=tm["reaction_wall_s"] - tm0["reaction_wall_s"])
+                rebuilds_timed=tm["rebuilds"] - tm0["rebuilds"], list_builds_timed=tm["list_rebuilds"] - tm0["list_rebuilds"],
+                reaction_wall_s=tm["reaction_wall_s"] - tm0["reaction_wall_s"])
     return eng, info
 
 
@@ -235,6 +241,32 @@ def spawn_ranks(nranks):
     return res.returncode
 
 
+def late_stage_leg(eng, a, n_reaction_steps=10):
+    """The gelled regime reactive runs spend most of their life in: advance (untimed) through `n_reaction_steps` more
+    reaction steps, then time max(K, 400) steps that start right behind a reaction step (so that none falls inside) with
+    the same per-kernel HIP-event sampling as the headline region."""
+    togo = n_reaction_steps * a.interval - (eng.step % a.interval)
+    eng.run(togo)
+    eng.sync()
+    k = min(max(a.steps, 400), a.interval - 1)
+    tm0 = eng.timers()
+    eng.set_option("time_pair_kernel", max(5, k // 256))
+    t0 = time.perf_counter()
+    eng.run(k)
+    eng.sync()
+    wall = time.perf_counter() - t0
+    tm = eng.timers()
+    eng.set_option("time_pair_kernel", 0)
+    obs = eng.observe()
+    bonds = int(sum(obs["list_size"]))
+    share = time_share(tm, k)
+    ks = kernel_rooflines(a, tm, k / wall, a.precision)
+    return dict(value=k / wall, unit="steps/s", steps=k, ms_per_step=1e3 * wall / k, at_step=int(eng.step), reaction_steps_before=int(tm0["reaction_steps"]),
+                bonds=bonds, conversion=bonds / (0.5 * a.n), events=int(len(eng.get_events())), list_rebuilds_timed=int(tm["rebuilds"] - tm0["rebuilds"]),
+                device_us_per_step=dict(pair=share["pair"], neighbour_kernel=share["neighbour"], integrate=share["integrate"], bonded=share["bonded"]),
+                kernels=[dict(kernel=q["kernel"], avg_launch_us=q["avg_launch_us"], frac=q["frac"], launches_sampled=q["launches_sampled"]) for q in ks])
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -256,7 +288,7 @@ def main():
             print(json.dumps(dict(rendezvous="ok", n_gpus=world, max_rank=int(top), node_grid=list(multigpu.node_grid(world)))))
         dist.barrier()
         return 0
-    spec = W.reactive_melt(n=a.n, rho=a.rho, interval=a.interval, seed=2)
+    spec = W.reactive_melt(n=a.n, rho=a.rho, interval=a.interval, seed=2, skin=a.skin)
     if world > 1 or os.environ.get("CHEM_FORCE_DD"):   # CHEM_FORCE_DD: exercise the RCCL slab path with one rank
         from chemlab_amd import multigpu
         return multigpu.bench_main(a, spec, rank, local_rank, world)
@@ -270,11 +302,11 @@ def main():
                n_gpus=1, steps=a.steps, warmup=a.warmup, ms_per_step=ms_per_step,
                higher_is_better=True, scaling="strong", vs_baseline=None,
                dtype="f32" if a.precision == 32 else "f64", data="synthetic",
-               config=dict(workload=WORKLOAD % (a.n, a.rho, a.interval, a.equil),
+               config=dict(workload=WORKLOAD % (a.n, a.rho, a.skin, a.interval, a.equil),
                            particles=a.n, reaction_interval=a.interval, equilibration_steps=a.equil,
                            msd_after_melting=info.get("msd_after_melting"),
                            reaction_steps_timed=int(info["reaction_steps_timed"]), reaction_events=int(info["events"]),
-                           list_rebuilds_timed=int(info["rebuilds_timed"]),
+                           list_rebuilds_timed=int(info["rebuilds_timed"]), list_builds_timed=int(info["list_builds_timed"]),
                            tau_per_day=steps_per_s * spec["dt"] * 86400, parallelism="1 GPU, single domain"))
     if info["reaction_steps_timed"] > 0:
         out["config"]["reaction_step_ms"] = 1e3 * info["reaction_wall_s"] / info["reaction_steps_timed"]
@@ -306,6 +338,9 @@ def main():
             nb = tm["nlist_entries"] / float(a.n)
             rl["whole_step_frac"] = a.n * (36.0 + 2.0 * nb + 80.0) * steps_per_s / HBM_PEAK
             out["roofline"] = rl
+    if a.late_stage > 0 and not a.no_roofline:
+        # `conversion` = chain bonds per A bead (n/2 of them); the headline region above has none yet
+        out["late_stage"] = late_stage_leg(eng, a, a.late_stage)
     if a.verbose:
         print("timers:", json.dumps(tm), file=sys.stderr)
     melted = info["melted"]

@@ -87,7 +87,7 @@ class Timers(C.Structure):
                 ("decide_kernel_ms", C.c_double), ("decide_kernel_launches", C.c_int64),
                 ("nlist_entries_all", C.c_int64),
                 ("integrate_kernel_ms", C.c_double), ("integrate_kernel_launches", C.c_int64),
-                ("bonded_kernel_ms", C.c_double), ("bonded_kernel_launches", C.c_int64)]
+                ("bonded_kernel_ms", C.c_double), ("bonded_kernel_launches", C.c_int64), ("list_rebuilds", C.c_int64)]
 
 
 _P = C.c_void_p

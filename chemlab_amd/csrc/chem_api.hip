@@ -145,6 +145,12 @@ struct Ctx {
   int opt_overlap = -1;     // decomposed path: interior forces while the halo exchange is in flight (-1: automatic, by slab size)
   hipStream_t cstream = nullptr; hipEvent_t ev_fold = nullptr, ev_halo = nullptr;
   int opt_criterion = 0;     // 1: rebuild when max |x - x(last build)| > skin/2 ; 0: reference's accumulated per-step maxima
+  // Internal list skin (>= the workload's skin): cells, tiles and the 16-bit force list are built for rc + skin_list and live
+  // until the accumulated displacement exceeds skin_list / 2.  Forces do not depend on it (exact cutoff in the force kernel);
+  // the reported rebuild count stays the reference rule's (DevCtl::ref_rebuilds).  opt_list_skin: < 0 automatic, 0 off
+  // (= the workload's skin), > 0 explicit.  Only the fused single-domain tile path uses it.
+  double opt_list_skin = -1.0, skin_list = 0.0;
+  double skin_eff() const { return skin_list > skin ? skin_list : skin; }
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
   // slab domain decomposition (chem_comm_init)
@@ -274,7 +280,7 @@ template <typename R> struct CtxT : Ctx {
 
   // ---- uploads ------------------------------------------------------------------------
   void setup_box() {
-    const double rl = rc + skin;
+    const double rl = rc + skin_eff();
     int nc[3]; bool cells = true;
     for (int d = 0; d < 3; ++d) { nc[d] = (int)std::floor(L[d] / rl); if (nc[d] < 3) cells = false; }
     for (int d = 0; d < 3; ++d) {
@@ -301,11 +307,32 @@ template <typename R> struct CtxT : Ctx {
   }
 
   // cells, neighbour-list capacity and everything else that depends on box/cutoff/skin
+  // Automatic list skin (measured on the 1M-particle melt, profiles/round3_list_skin.txt): two cells fewer per axis than the
+  // workload's skin would give, i.e. ~0.2 sigma more skin at rc + skin = 2.8 -- the lists live ~60 % longer for ~20 % more
+  // entries -- and always the whole cell edge (the slack between L / floor(L / rl) and rl is free skin).
+  double pick_list_skin() const {
+    if (opt_list_skin == 0.0 || opt_criterion != 0 || dd_on || !opt_fused || !opt_tiles) return 0.0;
+    const double rl = rc + skin;
+    double edge = 1e300;
+    for (int d = 0; d < 3; ++d) {
+      int nc = (int)std::floor(L[d] / (opt_list_skin > 0 ? rc + opt_list_skin : rl));
+      if (opt_list_skin < 0) { if (n < 100000) return 0.0; nc -= 2; }
+      if (nc < 5) return 0.0;
+      edge = std::min(edge, L[d] / nc);
+    }
+    const double s = edge * (1.0 - 1e-9) - rc;
+    return s > skin ? s : 0.0;
+  }
   void setup_geometry() {
+    skin_list = pick_list_skin();
+    setup_geometry_once();
+    if (skin_list > 0 && !use_fused) { skin_list = 0.0; setup_geometry_once(); }   // the wider skin only pays on the fused tile path
+  }
+  void setup_geometry_once() {
     setup_box();
     cell_cnt.alloc(box.ncell + 1); cell_start.alloc(box.ncell + 1); cell_sub.alloc(box.ncell + 2);
     HIPCHK(hipMemsetAsync(cell_cnt.p, 0, sizeof(int) * (box.ncell + 1), stream));
-    const double vol = L[0] * L[1] * L[2], rl = rc + skin;
+    const double vol = L[0] * L[1] * L[2], rl = rc + skin_eff();
     const double expect = 4.0 / 3.0 * M_PI * rl * rl * rl * (dd_on ? nglob : n) / vol;
     int ncap = nl_capacity_user > 0 ? nl_capacity_user : (int)(expect * 1.6 + 48);
     ncap = std::min(ncap, std::max((dd_on ? nglob : n) - 1, 1));
@@ -394,7 +421,8 @@ template <typename R> struct CtxT : Ctx {
     FusedArgs<R> a{};
     a.n = n; a.ncell = box.ncell; a.ntiles = ntiles; a.CAP = tile_cap; a.S = S; a.has_excl = has_excl; a.criterion = opt_criterion;
     a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = cdiv(n, kIntPerBlock); a.want32 = want32 ? 1 : 0; a.ntypes = ntypes; a.ablate = dbg_on ? opt_ablate_list : 0;
-    a.half_skin = 0.5 * skin; a.rl2 = (R)((rc + skin) * (rc + skin));
+    a.half_skin = 0.5 * skin_eff(); a.rl2 = (R)((rc + skin_eff()) * (rc + skin_eff()));
+    a.half_skin_ref = 0.5 * skin; a.rl2_rows = (R)((rc + skin) * (rc + skin));
     a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
     a.cell_cnt = cell_cnt.p; a.cell_of = cell_of.p; a.slot_of = slot_of.p; a.cell_start = cell_start.p; a.cell_loc = cell_loc.p;
@@ -983,7 +1011,7 @@ template <typename R> struct CtxT : Ctx {
   }
 
   template <bool ENERGY> int launch_pair(V4* fdst, int tpp) {
-    const double hs = 0.5 * skin;
+    const double hs = 0.5 * skin_eff();
     if (use_tiles) {
       // which tiles: all (default), or the interior / boundary subset of a slab (see TileSub)
       const int ntxy = ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY);
@@ -1073,7 +1101,8 @@ template <typename R> struct CtxT : Ctx {
               (g.stamp[3] - g.stamp[2]) * 0.01, (g.stamp[4] - g.stamp[3]) * 0.01, (g.stamp[5] - g.stamp[4]) * 0.01, (g.stamp[6] - g.stamp[5]) * 0.01);
     }
     if (dd_on) agree_flags(h);
-    tm.rebuilds = dd_on ? dd_rebuilds : h.rebuild_count;
+    tm.rebuilds = dd_on ? dd_rebuilds : h.ref_rebuilds;   // the reference rule's count (== rebuild_count unless a wider list skin is in use)
+    tm.list_rebuilds = dd_on ? dd_rebuilds : h.rebuild_count;
     if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
     if (h.bonded_missing) throw ChemError(CHEM_ESTATE, "domain decomposition: a bonded partner is farther than the ghost layer (rc+skin)");
     if (h.stage_overflow) throw ChemError(CHEM_ENOSPC, "cell stencil exceeded the LDS tile capacity (" + std::to_string(h.stage_overflow) + " particles)");
@@ -1305,7 +1334,7 @@ template <typename R> struct CtxT : Ctx {
       const int region_cap = std::max(1, cand_cap / std::max(ntiles, 1));
       tile_cnt.alloc(ntiles + 1); tile_off.alloc(ntiles + 1);
       hipLaunchKernelGGL((k_react_scan_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, state.p,
-                         res_id.p, mol_id.p, boxd, rs_dev.p, evout.p, region_cap, tile_cnt.p, ctl.p, (R)(0.5 * skin),
+                         res_id.p, mol_id.p, boxd, rs_dev.p, evout.p, region_cap, tile_cnt.p, ctl.p, (R)(0.5 * skin_eff()),
                          has_excl ? (const int*)excl_start.p : (const int*)nullptr, (const int*)excl_list.p);
       hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, stream, ntiles, tile_cnt.p, tile_off.p, ctl.p);
       hipLaunchKernelGGL(k_cand_gather, dim3(std::min(ntiles, 2048)), dim3(256), 0, stream, ntiles, evout.p, region_cap, tile_cnt.p, tile_off.p, cdst, cand_cap, ctl.p);
@@ -2272,7 +2301,8 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "overlap_halo") CTX.opt_overlap = value < 0 ? -1 : (value != 0 ? 1 : 0);
   else if (k == "pair_block") { const int v = (int)value; REQUIRE(v == 256 || v == 512 || v == 1024, CHEM_EINVAL, "pair_block must be 256, 512 or 1024"); CTX.set_pair_bs(v); }
   else if (k == "ablate") CTX.opt_ablate = (int)value;
-  else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; }
+  else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; CTX.geom_dirty = true; }
+  else if (k == "list_skin") { CTX.opt_list_skin = value; CTX.geom_dirty = true; CTX.resort = true; }
   else if (k == "debug_stamps") CTX.debug_enable((int)value);
   else if (k == "dd_self") {   // testing: one rank, ghost layers in z exchanged with itself by device copies
     REQUIRE(CTX.particles_dirty && !CTX.dd_on, CHEM_ESTATE, "dd_self must be set before the first run");

@@ -62,6 +62,11 @@ struct DevCtl {
   unsigned long long bw64;            // bonded work list: owners (low word) and entries (high word), one atomic per chunk
   int excl_slot_error;                // list build: an excluded partner was not found in the cell computed from its position (internal)
   int bucket_overflow;                // fused rebuild: a cell holds more particles than a bucket row (value = needed capacity)
+  // Rebuild count of the REFERENCE rule (accumulated per-step maxima against the workload's skin/2, reset by every forced
+  // rebuild): what chem_get_timers reports.  With an internal list skin wider than the workload's (option list_skin) the
+  // lists are rebuilt less often than that; forces do not depend on it (the force kernel applies the exact cutoff).
+  int ref_rebuilds;
+  double acc_ref;
 };
 
 template <typename R> struct Box {
@@ -215,8 +220,8 @@ __global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned l
     if (phase & 2) {
       double acc = criterion ? sqrt(m2) : ctl->acc_maxdist + sqrt(m2);
       const int need = (acc > half_skin) || ctl->force_rebuild;
-      if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
-      ctl->acc_maxdist = acc;
+      if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; ctl->ref_rebuilds++; }
+      ctl->acc_maxdist = acc; ctl->acc_ref = acc;
       ctl->need_rebuild = need;
       if (host_flag) {   // pinned, host-visible: [0] decision, [1] ticket (written last); the host spins on the ticket
         host_flag[0] = need;
@@ -1319,7 +1324,8 @@ template <typename R, int BS>
 __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* const sx, const int* tag, const R rl2,
                                                const int* excl_start, const int* excl_list, const int has_excl, const ActMask& act,
                                                unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl,
-                                               const Box<R>* bx = nullptr, const int* rtag = nullptr, const Vec4<R>* x4 = nullptr) {
+                                               const Box<R>* bx = nullptr, const int* rtag = nullptr, const Vec4<R>* x4 = nullptr, const R rl2_rows_ = (R)-1) {
+    const R rl2_rows = rl2_rows_ > (R)0 ? rl2_rows_ : rl2;   // int32 Verlet rows: the workload's rc+skin (see dev_nlist_tile_f32)
     const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4], hbase = T.geom[5];
     unsigned short* reg16 = nl16 + (size_t)hbase * S16;
     for (int q = threadIdx.x; q < nhome; q += BS) {
@@ -1361,7 +1367,11 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
         }
         if (ok) {
           if ((arow >> (jw & 15)) & 1u) push((unsigned int)s);
-          if (row32) { if (cnt < S) row32[cnt] = j; ++cnt; }
+          if (row32) {
+            bool in_rows = true;
+            if (rl2_rows < rl2) { const Vec4<R> xj = sx[s]; const R dx = xi.x - xj.x, dy_ = xi.y - xj.y, dz_ = xi.z - xj.z; in_rows = dx * dx + dy_ * dy_ + dz_ * dz_ <= rl2_rows; }
+            if (in_rows) { if (cnt < S) row32[cnt] = j; ++cnt; }
+          }
         }
       };
       // Two passes per x-run segment of <= 64 staged candidates:
@@ -1454,7 +1464,8 @@ template <typename RS, int BS>
 __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigned char* lds, const ListLDS& L, const int* tag, const float rl2,
                                                    const int* excl_start, const int* excl_list, const int has_excl,
                                                    unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl,
-                                                   const Box<RS>* bx, const int* rtag, const Vec4<RS>* x4, const int ablate = 0) {
+                                                   const Box<RS>* bx, const int* rtag, const Vec4<RS>* x4, const int ablate = 0, const float rl2_rows_ = -1.f) {
+  const float rl2_rows = rl2_rows_ > 0.f ? rl2_rows_ : rl2;   // int32 Verlet rows: the workload's rc+skin (the 16-bit force list may use a wider list skin)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   typedef __attribute__((address_space(3))) const volatile f32x4 lds_f32x4;   // volatile: keeps the 16-byte reads and their order
@@ -1630,7 +1641,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
             const int j = T.cellg[r][kc] + (e - T.celloff[r][kc]);
             const CHEM_LDS float* cj = img + (sl >> 2) * kGrpF + (sl & 3);
             const float ddx = xix - cj[0], ddy = xiy - cj[4], ddz = xiz - cj[8];
-            const bool exact = ddx * ddx + ddy * ddy + ddz * ddz <= rl2;  // difference form: the mask is a superset by the delta shell
+            const bool exact = ddx * ddx + ddy * ddy + ddz * ddz <= rl2_rows;  // difference form: the mask is a superset by the delta shell
             bool ok = true;
             if (e1 > e0) {
               const int tgj = tag[j];
@@ -2208,6 +2219,7 @@ __device__ __forceinline__ bool grid_barrier(GridBar* gb, DevCtl* ctl) {
 template <typename R> struct FusedArgs {
   int n, ncell, ntiles, CAP, S, has_excl, criterion, par, seg_shift, tseg_shift, nblk, want32, ntypes, ablate;
   double half_skin; R rl2;
+  double half_skin_ref; R rl2_rows;    // the workload's skin: reference rebuild count, radius of the int32 Verlet rows (rl2 / half_skin: list skin)
   Vec4<R> *x4, *v4, *x4o, *v4o, *x0;
   int *tag, *tago, *rtag; int4 *img4, *img4o;
   int *cell_cnt, *cell_of, *slot_of, *cell_start, *cell_loc, *btot, *perm, *tn, *tloc, *tbtot, *cell_sub, *cell_n, *bucket; int bcap;
@@ -2288,9 +2300,17 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
   for (int k = 1; k < BS / 64; ++k) m = s_m[k] > m ? s_m[k] : m;
   const double m2 = sizeof(R) == 4 ? bits_real_f(m) : bits_real_d(m);
   double acc = a.criterion ? sqrt(m2) : ctl->acc_pp[a.par] + sqrt(m2);
-  const int need = (acc > a.half_skin) || ctl->force_rebuild;
+  const int forced = ctl->force_rebuild;
+  const int need = (acc > a.half_skin) || forced;
+  // reference rule on the workload's skin (bookkeeping of thread (0,0) only: nobody else reads these two words)
+  auto ref_update = [&]() {
+    const double accr = a.criterion ? sqrt(m2) : ctl->acc_ref + sqrt(m2);
+    const bool rn = (accr > a.half_skin_ref) || forced;
+    ctl->acc_ref = rn ? 0.0 : accr;
+    if (rn) ctl->ref_rebuilds++;
+  };
   if (!need) {
-    if (b == 0 && t == 0) { ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = acc; ctl->acc_maxdist = acc; ctl->need_rebuild = 0; }
+    if (b == 0 && t == 0) { ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = acc; ctl->acc_maxdist = acc; ctl->need_rebuild = 0; ref_update(); }
     return;
   }
 
@@ -2318,6 +2338,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
   if (b == 0 && t == 0) {
     ctl->step_m2 = m2; ctl->acc_pp[a.par ^ 1] = 0.0; ctl->acc_maxdist = 0.0; ctl->force_rebuild = 0;
     ctl->rebuild_count++; ctl->need_rebuild = 1;
+    ref_update();
   }
 
   // ---- P4: cell_start, canonical order inside every cell + gather + tag -> index map; home count of every tile ----
@@ -2418,12 +2439,12 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
         if (ablate == 1) { for (int q = t; q < T.geom[4]; q += BS) a.nnh[T.geom[5] + q] = 0; }
         else
         dev_nlist_tile_f32<R, BS>(T, chem_dyn_lds, L, a.tago, (float)a.rl2, a.excl_start, a.excl_list, a.has_excl, a.nl16, a.S, a.nnh,
-                               (DIAG && a.want32) ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, ablate);
+                               (DIAG && a.want32) ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, ablate, (float)a.rl2_rows);
       } else {
         tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
         __syncthreads();
         dev_nlist_tile<R, BS>(T, sx, a.tago, a.rl2, a.excl_start, a.excl_list, a.has_excl, a.act, a.nl16, a.S, a.nnh,
-                              a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o);
+                              a.want32 ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, a.rl2_rows);
       }
     }
     WGST(6);

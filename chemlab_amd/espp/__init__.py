@@ -1144,4 +1144,147 @@ class _DumpGRO(object):
     perform_action = dump
 
 
-io = _ns(DumpH5MD=_unsupported("io.DumpH5MD (h5py is not available in this image)"), DumpTopology=_unsupported("io.DumpTopology (H5MD)"), DumpGRO=_DumpGRO)
+class _DumpH5MD(object):
+    """io.DumpH5MD(system, filename, group_name='atoms', store_species=..., store_state=..., ...) -- the trajectory writer
+    of start_simulation.py:571-589: dump(step, time) appends one frame, flush() writes the file, close().
+    Layout = the H5MD tree analysis scripts read (examples/chain_growth_catalytic/Checkup.ipynb,
+    examples/mf/espp_cg_1_water/analyze.py:20-24):
+        /particles/<group>/{position,image,species,state,res_id,mass,id,velocity,force}/{value,step,time}   value: [frames, N(, 3)]
+        /particles/<group>/box/edges/{value,step,time}                                                   value: [frames, 3]
+        /connectivity/<name>/{value,step,time}     value: [frames, max entries, arity], unused rows filled with -1
+    With h5py importable the file is real HDF5; otherwise (this image) the same tree is written as a NumPy .npz archive
+    whose keys are the dataset paths (`<filename minus .h5>.npz`); tools/npz2h5md.py turns it into the .h5 file."""
+
+    def __init__(self, system, filename, group_name="atoms", static_box=True, author="", email="", store_species=True, store_res_id=True,
+                 store_charge=False, store_position=True, store_state=True, store_lambda=False, store_force=False, store_velocity=False,
+                 store_mass=True, is_single_prec=True, chunk_size=256, **kw):
+        self.system, self.filename, self.group = system, filename, group_name
+        self.store = dict(species=store_species, res_id=store_res_id, position=store_position, state=store_state, force=store_force,
+                          velocity=store_velocity, mass=store_mass)
+        self.real = np.float32 if is_single_prec else np.float64
+        self.frames = {}            # dataset path -> list of per-frame arrays
+        self.steps, self.times = [], []
+        self.connectivity = {}      # name -> dict(value=[...], step=[...], time=[...], arity)
+        self.static_connectivity = {}
+
+    def _add(self, name, arr):
+        self.frames.setdefault("particles/%s/%s/value" % (self.group, name), []).append(arr)
+
+    def dump(self, step, time_):
+        e = self.system.engine
+        self.steps.append(int(step)); self.times.append(float(time_))
+        self._add("id", e.get_state("ID").astype(np.int64))
+        if self.store["position"]:
+            self._add("position", e.get_state("POS").astype(self.real))
+            self._add("image", e.get_state("IMAGE").astype(np.int32))
+        if self.store["velocity"]:
+            self._add("velocity", e.get_state("VEL").astype(self.real))
+        if self.store["force"]:
+            self._add("force", e.get_state("FORCE").astype(self.real))
+        if self.store["species"]:
+            self._add("species", e.get_state("TYPE").astype(np.int32))
+        if self.store["state"]:
+            self._add("state", e.get_state("STATE").astype(np.int32))
+        if self.store["res_id"]:
+            self._add("res_id", e.get_state("RESID").astype(np.int32))
+        if self.store["mass"]:
+            self._add("mass", e.get_state("MASS").astype(self.real))
+        self.frames.setdefault("particles/%s/box/edges/value" % self.group, []).append(np.asarray(list(self.system.bc.boxL), dtype=self.real))
+
+    def tree(self):
+        """dataset path -> array, as written by flush()."""
+        out = {}
+        st, tm = np.asarray(self.steps, dtype=np.int64), np.asarray(self.times, dtype=np.float64)
+        for path, fr in self.frames.items():
+            out[path] = np.stack(fr) if fr else np.zeros((0,))
+            base = path[:-len("/value")]
+            out[base + "/step"], out[base + "/time"] = st[:len(fr)], tm[:len(fr)]
+        for name, c in self.connectivity.items():
+            rows = max([len(v) for v in c["value"]] + [1])
+            val = -np.ones((len(c["value"]), rows, c["arity"]), dtype=np.int64)
+            for k, v in enumerate(c["value"]):
+                if len(v):
+                    val[k, :len(v)] = v
+            out["connectivity/%s/value" % name] = val
+            out["connectivity/%s/step" % name] = np.asarray(c["step"], dtype=np.int64)
+            out["connectivity/%s/time" % name] = np.asarray(c["time"], dtype=np.float64)
+        for name, v in self.static_connectivity.items():
+            out["connectivity/%s" % name] = v
+        return out
+
+    def flush(self):
+        tree = self.tree()
+        try:
+            import h5py
+        except ImportError:
+            h5py = None
+        if h5py is not None:
+            with h5py.File(self.filename, "w") as h5:
+                for path, arr in tree.items():
+                    h5.create_dataset(path, data=arr)
+            return self.filename
+        out = self.filename[:-3] + ".npz" if self.filename.endswith(".h5") else self.filename + ".npz"
+        np.savez_compressed(out, **tree)
+        return out
+
+    def close(self):
+        return self.flush()
+
+
+class _DumpTopology(object):
+    """io.DumpTopology(system, integrator, h5md_file): observe_tuple/triple/quadruple(list, name) record the CURRENT entries of
+    a (growing) list at every dump() into /connectivity/<name> (-1 padded rows); add_static_* store a list once
+    (start_simulation.py:591-642).  Used through ExtAnalyze(dump_topol, topol_collect); update() is the reference's
+    flush-to-file hook (a no-op here: the trajectory object writes everything in flush())."""
+
+    def __init__(self, system, integrator, h5md_file):
+        self.system, self.integrator, self.h5 = system, integrator, h5md_file
+        self._observed = []
+
+    def _observe(self, lst, name, arity):
+        self._observed.append((lst, name))
+        self.h5.connectivity[name] = dict(value=[], step=[], time=[], arity=arity)
+
+    def observe_tuple(self, fpl, name):
+        self._observe(fpl, name, 2)
+
+    def observe_triple(self, ftl, name):
+        self._observe(ftl, name, 3)
+
+    def observe_quadruple(self, fql, name):
+        self._observe(fql, name, 4)
+
+    @staticmethod
+    def _entries(lst):
+        for getter in ("getAllBonds", "getAllTriples", "getAllQuadruples"):
+            if hasattr(lst, getter):
+                try:
+                    return np.asarray(getattr(lst, getter)(), dtype=np.int64)
+                except Exception:
+                    continue
+        return np.zeros((0, 2), dtype=np.int64)
+
+    def add_static_tuple(self, fpl, name):
+        self.h5.static_connectivity[name] = self._entries(fpl).reshape(-1, 2)
+
+    def add_static_triple(self, ftl, name):
+        self.h5.static_connectivity[name] = self._entries(ftl).reshape(-1, 3)
+
+    def add_static_quadruple(self, fql, name):
+        self.h5.static_connectivity[name] = self._entries(fql).reshape(-1, 4)
+
+    def dump(self):
+        step = self.integrator.step
+        for lst, name in self._observed:
+            c = self.h5.connectivity[name]
+            c["value"].append(self._entries(lst).reshape(-1, c["arity"]))
+            c["step"].append(int(step)); c["time"].append(float(step) * float(self.integrator.dt or 0.0))
+
+    perform_action = dump
+    perform = dump
+
+    def update(self):
+        pass
+
+
+io = _ns(DumpH5MD=_DumpH5MD, DumpTopology=_DumpTopology, DumpGRO=_DumpGRO)

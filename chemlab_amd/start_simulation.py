@@ -269,6 +269,29 @@ def main(argv=None, hooks=None, quiet=False):
     for i, (gname, fpl, _) in enumerate(chem_fpls):
         mon.add_observable("count_%d" % i, espressopp.analysis.NFixedPairListEntries(system, fpl))
     integrator.addExtension(espressopp.integrator.ExtAnalyze(mon, cad["energy_collect"]))
+    # trajectory + topology writer (start_simulation.py:571-657): H5MD tree, see espp._DumpH5MD for the on-disk form
+    traj_file = espressopp.io.DumpH5MD(
+        system, "%s_%s_traj.h5" % (args.output_prefix, rng_seed), group_name="atoms", static_box=True,
+        store_species=args.store_species, store_res_id=args.store_res_id, store_charge=args.store_charge, store_position=args.store_position,
+        store_state=args.store_state, store_lambda=args.store_lambda, store_force=args.store_force, store_velocity=args.store_velocity,
+        store_mass=args.store_mass, is_single_prec=args.store_single_precision, chunk_size=256)
+    dump_topol = espressopp.io.DumpTopology(system, integrator, traj_file)
+    for i, (gname, fpl, _) in enumerate(chem_fpls):
+        dump_topol.observe_tuple(fpl, "chem_bonds_%d" % i)                     # :592-593, read back by Checkup.ipynb / analyze.py
+    for kind, lists, add_static, observe, label in (("bond", bonded, dump_topol.add_static_tuple, dump_topol.observe_tuple, "bonds"),
+                                                    ("angle", angles, dump_topol.add_static_triple, dump_topol.observe_triple, "angles"),
+                                                    ("dihedral", dihedrals, dump_topol.add_static_quadruple, dump_topol.observe_quadruple, "dihedrals")):
+        for cnt, (name, (fl, _inter)) in enumerate(sorted(lists.items())):     # :595-642
+            if name.endswith("_dynamic") and args.store_angdih:
+                observe(fl, "dynamic_%s_%d" % (label, cnt))
+            else:
+                add_static(fl, "%s_%d" % (label, cnt))
+    save_traj_topology = args.save_before_reaction if cad["k_enable_reactions"] > 1 else True     # :649
+    ext_dump_added = False
+    if args.topol_collect > 0 and save_traj_topology:
+        integrator.addExtension(espressopp.integrator.ExtAnalyze(dump_topol, cad["topol_collect"]))
+        ext_dump_added = True
+        dump_topol.dump(); dump_topol.update()
     espressopp.analysis.CMVelocity(system).reset()
     maximum_conversion, eq_run = [], 0                    # start_simulation.py:280-287
     if args.maximum_conversion and ar is not None:
@@ -284,6 +307,11 @@ def main(argv=None, hooks=None, quiet=False):
         hooks["hook_before_sim"](system, integrator, ar, gt)
     for k in range(cad["sim_step"]):
         mon.info() if not quiet else None
+        if save_traj_topology and cad["k_trj_collect"] > 0 and k % cad["k_trj_collect"] == 0:      # start_simulation.py:730-731
+            traj_file.dump(k * cad["integrator_step"], k * cad["integrator_step"] * args.dt)
+        if save_traj_topology and cad["k_trj_flush"] > 0 and k % cad["k_trj_flush"] == 0:          # :732-734
+            dump_topol.update()
+            traj_file.flush()
         if cad["k_enable_reactions"] == k and ar is not None:
             log("Enabling chemical reactions")
             integrator.addExtension(ar)
@@ -294,6 +322,12 @@ def main(argv=None, hooks=None, quiet=False):
             outputs.write_gro("%s_%s_before_reaction_confout.gro" % (args.output_prefix, args.rng_seed), conf, pos, conf.box, velocities=vel)
             if "hook_init_reaction" in hooks and not hooks["hook_init_reaction"](system, integrator, ar, gt, args):
                 raise RuntimeError("hook_init_reaction return False")
+            if not save_traj_topology:                                                             # start_simulation.py:750-757
+                save_traj_topology = True
+                if not ext_dump_added:
+                    integrator.addExtension(espressopp.integrator.ExtAnalyze(dump_topol, cad["topol_collect"]))
+                    ext_dump_added = True
+                dump_topol.dump(); dump_topol.update()
         if reactions_enabled:
             if not stop_simulation:                        # start_simulation.py:759-770
                 for obs, stop_value in maximum_conversion:
@@ -316,6 +350,10 @@ def main(argv=None, hooks=None, quiet=False):
     if "hook_end" in hooks:
         hooks["hook_end"](system, integrator, ar, gt, args)
     mon.info() if not quiet else None
+    nsteps_total = cad["sim_step"] * cad["integrator_step"]                                        # start_simulation.py:802-807
+    traj_file.dump(nsteps_total, nsteps_total * args.dt)
+    dump_topol.dump(); dump_topol.update()
+    traj_path = traj_file.close()
     write_final_outputs(args, system, gt, conf, bonded, angles, dihedrals, chem_fpls, topology_manager, ar, reaction_index)
     for ext in integrator_extensions:
         if hasattr(ext, "save_stats"):
@@ -325,7 +363,7 @@ def main(argv=None, hooks=None, quiet=False):
         f.write("%d %d %s %s\n" % (1, npart, total_time, integrator_loop))
     log("finished: %d steps, integratorLoop %.3f s, %.1f steps/s" % (cad["sim_step"] * cad["integrator_step"], integrator_loop,
                                                                        cad["sim_step"] * cad["integrator_step"] / max(integrator_loop, 1e-12)))
-    return dict(system=system, integrator=integrator, gt=gt, ar=ar, chem_fpls=chem_fpls, cadence=cad, args=args,
+    return dict(system=system, integrator=integrator, gt=gt, ar=ar, chem_fpls=chem_fpls, cadence=cad, args=args, trajectory=traj_path,
                 total_time=total_time, integrator_loop=integrator_loop, bonded=bonded, angles=angles, dihedrals=dihedrals, monitor=mon,
                 stopped_by_conversion=stop_simulation)
 

@@ -155,6 +155,9 @@ typedef struct chem_timers {
   int64_t integrate_kernel_launches;
   double  bonded_kernel_ms;
   int64_t bonded_kernel_launches;
+  /* list builds actually performed (`rebuilds` above counts the reference rule on the workload's skin; with a wider internal
+   * list skin -- option list_skin -- the lists are rebuilt less often) */
+  int64_t list_rebuilds;
 } chem_timers;
 
 /* ---- life cycle ---------------------------------------------------------------------- */

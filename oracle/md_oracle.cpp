@@ -1069,7 +1069,7 @@ int orc_compute_forces(void* c) {
   return 0;
 }
 
-int orc_get_timers(void* c, chem_timers* t) { Orc& o = O(c); materialise_pairs(o); std::memset(t, 0, sizeof(*t)); t->steps = o.step; t->rebuilds = o.rebuilds; t->reaction_steps = o.reaction_steps; t->nlist_entries = 2 * (int64_t)o.pairs.size(); return 0; }
+int orc_get_timers(void* c, chem_timers* t) { Orc& o = O(c); materialise_pairs(o); std::memset(t, 0, sizeof(*t)); t->steps = o.step; t->rebuilds = o.rebuilds; t->list_rebuilds = o.rebuilds; t->reaction_steps = o.reaction_steps; t->nlist_entries = 2 * (int64_t)o.pairs.size(); return 0; }
 
 }  // extern "C"
 

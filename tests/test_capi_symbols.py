@@ -31,7 +31,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_capi.ReactionDesc) == 120
     assert C.sizeof(_capi.Event) == 40
     assert C.sizeof(_capi.Obs) == 8 * 6 + 8 * 32 * 2 + 8 * 4
-    assert C.sizeof(_capi.Timers) == 80 + 9 * 8   # + per-kernel event samples (round 2)
+    assert C.sizeof(_capi.Timers) == 80 + 9 * 8 + 8   # + per-kernel event samples (round 2) + list_rebuilds (round 3)
 
 
 def test_no_cpu_fallback_without_gpu():

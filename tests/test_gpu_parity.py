@@ -480,9 +480,9 @@ def test_dd_multi_rank_in_process_reactive(make_gpu, make_oracle, chunks):
 @pytest.mark.parametrize("example,argv,min_events", [
     ("chain_growth_catalytic", ["@params", "--run=2500", "--start_ar=500"], 100),
     ("mf_espp_cg_1", ["@params", "--run=3000", "--start_ar=1000", "--int_step=500", "--energy_collect=500", "--trj_collect=1000", "--rng_seed=7"], 5),
-    # C1 (BASELINE configs[0]): examples/atrp_lj with its ChangeNeighboursProperty extension; the ATRPActivator is out of
-    # scope, a hooks.py (start_simulation.py:214-228) creates the initiators the way examples/atrp_lj/hooks.py does
-    ("atrp_lj", ["@params", "--run=1000", "--maximum_conversion=", "--rng_seed=11"], 5)])
+    # C1 (BASELINE configs[0]): examples/atrp_lj with its atrp.cfg UNMODIFIED (ATRPActivator + ChangeNeighboursProperty);
+    # a hooks.py (start_simulation.py:214-228) creates dormant initiators (FA in state 2) the way examples/atrp_lj/hooks.py does
+    ("atrp_lj", ["@params", "--run=3000", "--maximum_conversion=", "--rng_seed=11"], 10)])
 def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mod, example, argv, min_events):
     """The py3 start_simulation driver (readers -> espressopp-shaped shim -> C ABI) on shipped example inputs
     (LJ chain growth; tabulated non-bonded melt with Langevin at 800 K; ATRP trimer melt with neighbour property changes and
@@ -496,14 +496,12 @@ def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mo
         d = tmp_path / name
         shutil.copytree(gold, str(d))
         if example == "atrp_lj":
-            cfg = (d / "atrp.cfg").read_text().replace("extensions=atrp,change_neighbour_type", "extensions=change_neighbour_type")
-            (d / "atrp.cfg").write_text(cfg)
             os.makedirs(str(d / "data"), exist_ok=True)
             (d / "hooks.py").write_text(
                 "def hook_init_reaction(system, integrator, ar, topol, args):\n"
                 "    n2t = topol.atomsym_atomtype\n"
                 "    for mol in range(40):\n"
-                "        for k, (name, state) in enumerate((('FA', 3), ('PL', 2), ('PA', None))):\n"
+                "        for k, (name, state) in enumerate((('FA', 2), ('PL', 2), ('PA', None))):\n"
                 "            pid = 3 * mol * 7 + 1 + k\n"
                 "            system.storage.modifyParticle(pid, 'type', n2t[name])\n"
                 "            system.storage.modifyParticle(pid, 'mass', topol.gt.atomtypes[name]['mass'])\n"
@@ -518,12 +516,17 @@ def test_driver_on_gpu_matches_driver_on_oracle(tmp_path, monkeypatch, oracle_mo
             espp.set_engine_factory(lambda: Engine(device=0, precision=32))
         e = res["system"].engine
         out[name] = dict(ev=sorted_events(e.get_events()), bonds=res["chem_fpls"][0][1].getAllBonds(), st=e.get_state("STATE"),
-                         ty=e.get_state("TYPE"), x=e.get_state("POS_UNFOLDED"))
+                         ty=e.get_state("TYPE"), x=e.get_state("POS_UNFOLDED"), atrp=e.atrp_stats())
+        if example == "atrp_lj":
+            assert os.path.exists("data/cpc01_11_atrp_stats.dat")            # ATRPActivator.stats_filename
     assert len(out["oracle"]["ev"]) > min_events
     assert [v[:4] for v in out["gpu"]["ev"]] == [v[:4] for v in out["oracle"]["ev"]]
     assert out["gpu"]["bonds"] == out["oracle"]["bonds"]
+    assert out["gpu"]["atrp"] == out["oracle"]["atrp"] and (example != "atrp_lj" or sum(r["activated"] for r in out["oracle"]["atrp"]) >= 5)
     assert np.array_equal(out["gpu"]["st"], out["oracle"]["st"]) and np.array_equal(out["gpu"]["ty"], out["oracle"]["ty"])
-    assert rel_err(out["gpu"]["x"], out["oracle"]["x"]) < 1e-7
+    # (fp64 on both sides: summation order differs in the last bit and a melt amplifies that by ~e^(t/tau); the 3000-step
+    #  ATRP run (7.5 tau) ends at 2.5e-6, the discrete outcomes above are identical)
+    assert rel_err(out["gpu"]["x"], out["oracle"]["x"]) < (1e-7 if example != "atrp_lj" else 1e-4)
 
 
 # ---- edge cases and size-independent properties ---------------------------------------------------
