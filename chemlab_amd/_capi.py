@@ -119,6 +119,7 @@ SIGNATURES = {
     "reaction_init": (_i, [_P, _i, _i, _i, _u64]),
     "reaction_add": (_i, [_P, C.POINTER(ReactionDesc)]),
     "reaction_neighbour_change": (_i, [_P, C.POINTER(NbChange)]),
+    "reaction_restrict": (_i, [_P, _i, _i64, _pi64]),
     "atrp_init": (_i, [_P, C.POINTER(AtrpDesc)]),
     "atrp_add_center": (_i, [_P, _i, _i, _i, _i, _d, _d, _i]),
     "atrp_get_stats": (_i64, [_P, C.POINTER(AtrpStats), _i64]),

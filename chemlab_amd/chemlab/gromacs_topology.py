@@ -116,7 +116,7 @@ def gen_particle_list(coordinate, topol, espressopp):
     return props, plist
 
 
-def set_nonbonded_interactions(espressopp, system, gt, vl, lj_cutoff, tab_cutoff=None, tables_=None, table_dir="."):
+def set_nonbonded_interactions(espressopp, system, gt, vl, lj_cutoff, tab_cutoff=None, tables_=None, table_dir=".", cr_observs=None):
     """One VerletListLennardJones ('lj') and one VerletListTabulated ('lj-tab') for all type pairs
     (:463-899).  A pair gets no potential when sigma <= 0 (:715)."""
     tab_cutoff = lj_cutoff if tab_cutoff is None else tab_cutoff
@@ -124,7 +124,16 @@ def set_nonbonded_interactions(espressopp, system, gt, vl, lj_cutoff, tab_cutoff
     cr = int(gt.gt.defaults["combinationrule"])
     lj = espressopp.interaction.VerletListLennardJones(vl)
     tab = espressopp.interaction.VerletListTabulated(vl)
-    has_lj = has_tab = False
+    mix = espressopp.interaction.VerletListMixedTabulated(vl)
+    cr_observs = {} if cr_observs is None else cr_observs
+    has_lj = has_tab = has_mix = False
+
+    def pot_file(name):                                  # table.xvg -> table.pot next to it, converted when missing (:764-769)
+        xvg = os.path.join(table_dir, name)
+        pot = xvg.replace(".xvg", "") + ".pot"
+        if not os.path.exists(pot):
+            tables.convert_table(xvg, pot)
+        return pot
     names = list(gt.used_atomsym_atomtype)
     for i, n1 in enumerate(names):
         for n2 in names[i:]:
@@ -136,6 +145,21 @@ def set_nonbonded_interactions(espressopp, system, gt, vl, lj_cutoff, tab_cutoff
                     sig, eps = float(param["params"][0]), float(param["params"][1])
                 elif param["func"] == 8:
                     table_name = param["params"][0] if param["params"] else "table_%s_%s.xvg" % (n1, n2)
+                elif param["func"] in (10, 12):
+                    # func 10: `tab1 tab2 TYPE total` -- U = x tab1 + (1 - x) tab2 with x = (particles of TYPE) / total, the
+                    # chemical conversion (:574-583,770-778); func 12: `tab1 tab2 x` with a constant x (:612-618,779-786)
+                    pr = param["params"]
+                    if param["func"] == 10:
+                        cr_type, cr_total = gt.used_atomsym_atomtype[pr[2]], int(pr[3])
+                        key = (cr_type, cr_total, None)
+                        if key not in cr_observs:
+                            cr_observs[key] = espressopp.analysis.ChemicalConversion(system, cr_type, cr_total)
+                        pot = espressopp.interaction.MixedTabulated(1, pot_file(pr[0]), pot_file(pr[1]), cr_observs[key], cutoff=tab_cutoff)
+                    else:
+                        pot = espressopp.interaction.MixedTabulated(1, table1=pot_file(pr[0]), table2=pot_file(pr[1]), mix_value=float(pr[2]), cutoff=tab_cutoff)
+                    mix.setPotential(type1=t1, type2=t2, potential=pot)
+                    has_mix = True
+                    continue
                 else:
                     raise NotImplementedError("nonbond_params func %d is outside the hot-path scope (SURVEY.md 2.1 #3)" % param["func"])
             elif n1 in tables_ and n2 in tables_:
@@ -159,6 +183,8 @@ def set_nonbonded_interactions(espressopp, system, gt, vl, lj_cutoff, tab_cutoff
         system.addInteraction(lj, "lj")
     if has_tab:
         system.addInteraction(tab, "lj-tab")
+    if has_mix:
+        system.addInteraction(mix, "lj-mix_tab")
     return lj if has_lj else None, tab if has_tab else None
 
 

@@ -14,7 +14,8 @@ class SetupReactions(object):
     def _setup_reaction_normal(self, cr, fpl):
         e, rl = self.espp, cr["reactant_list"]
         n2t = self.name2type
-        r = e.integrator.Reaction(
+        r_class = e.integrator.RestrictReaction if cr.get("connectivity_map") else e.integrator.Reaction      # reaction_setup.py:75-78
+        r = r_class(
             type_1=n2t[rl["type_1"]["name"]], type_2=n2t[rl["type_2"]["name"]],
             delta_1=int(rl["type_1"]["delta"]), delta_2=int(rl["type_2"]["delta"]),
             min_state_1=int(rl["type_1"]["min"]), max_state_1=int(rl["type_1"]["max"]),
@@ -27,6 +28,15 @@ class SetupReactions(object):
         if "min_cutoff" in cr:
             r.get_reaction_cutoff().min_cutoff = float(cr["min_cutoff"])
         r.active = cr.get("active", True)
+        if cr.get("connectivity_map"):                       # id pairs `b1 b2`, one per line (reaction_setup.py:115-128)
+            conn = set()
+            with open(cr["connectivity_map"]) as f:
+                for line in f:
+                    if line.strip():
+                        b1, b2 = map(int, line.split())
+                        conn.add(tuple(sorted((b1, b2))))
+            for b1, b2 in sorted(conn):
+                r.define_connection(b1, b2)
         for which in ("type_1", "type_2"):
             old, new = rl[which]["name"], rl[which]["new_type"]
             if old != new:   # type change with the new type's mass and charge from [ atomtypes ]
@@ -112,6 +122,7 @@ class SetupReactions(object):
             self.system.addInteraction(inter, "fpl_%s" % gname)
             self.fpls.append((gname, fpl, inter))
             for cr in group["reaction_list"]:
+                cr["connectivity_map"] = group.get("connectivity_map")      # group level -> reaction level (reaction_setup.py:488)
                 r = self._setup_reaction_normal(cr, fpl)
                 for name, (pp, invoke_on) in group_pp:        # reaction_setup.py:495-505
                     if name not in cr.get("exclude_extensions", []):

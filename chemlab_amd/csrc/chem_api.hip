@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <memory>
 #include <thread>
 #include <mutex>
@@ -93,6 +94,8 @@ struct Ctx {
   int interval = 0, nearest = 1, max_per_interval = 0; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
   std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty (chem_reaction_neighbour_change)
+  // RestrictReaction.define_connection (chem_reaction_restrict): (tag lo, tag hi) -> reaction bits; CSR rebuilt when it changed
+  std::map<std::pair<int32_t, int32_t>, uint32_t> restrict_map; uint32_t restricted_mask = 0; bool restrict_dirty = false;
   // integrator.ATRPActivator (chem_atrp_init; reaction_post_process.py:380-426)
   struct AtrpCenter { int type, state, is_activator, new_type, delta_state; double new_mass, new_q; };
   bool atrp_on = false; chem_atrp_desc atrp{}; std::vector<AtrpCenter> atrp_centers; std::vector<chem_atrp_stats> atrp_stats;
@@ -191,6 +194,27 @@ template <typename R> struct CtxT : Ctx {
     const size_t lb = list_lds_bytes(tile_cap, kMaxTypes);
     return (sizeof(R) == 4 || exact_rows) ? std::max(tile_lds_bytes(), lb) : lb;
   }
+  // ---- position codec on the host (md_kernels.hpp "position codec"): fp32 build = int32 fixed point, fp64 build = reals
+  static constexpr bool kFixed = sizeof(R) == 4;
+  double q_scale(int d) const { return L[d] / 2147483648.0; }
+  R enc_pos(double x, int d) const {      // x already folded into [0, L)
+    if constexpr (kFixed) { const int32_t q = (int32_t)(long long)std::llrint((x - 0.5 * L[d]) / q_scale(d)); R r; std::memcpy(&r, &q, 4); return r; }
+    else return (R)x;
+  }
+  double dec_pos(R v, int d) const {
+    if constexpr (kFixed) { int32_t q; std::memcpy(&q, &v, 4); return (double)q * q_scale(d) + 0.5 * L[d]; }
+    else return (double)v;
+  }
+  R enc_shift(double boxes, int d) const {   // periodic shift of +-1 box length (slab ghost layers)
+    if constexpr (kFixed) { const uint32_t q = boxes != 0.0 ? 0x80000000u : 0u; R r; std::memcpy(&r, &q, 4); return r; }
+    else return (R)(boxes * L[d]);
+  }
+  static double fold_coord(double x, double Ld) { double s = std::floor(x / Ld); x -= s * Ld; if (x >= Ld) x -= Ld; if (x < 0) x = 0; return x; }
+  PosScale<R> pos_scale() const {
+    PosScale<R> ps{};
+    for (int d = 0; d < 3; ++d) { ps.s[d] = (R)q_scale(d); ps.inv[d] = (R)(1.0 / q_scale(d)); }
+    return ps;
+  }
   hipStream_t stream = nullptr;
   int n = 0;
   DBuf<V4> x4, v4, f4, x4o, v4o, tab, x0;
@@ -255,6 +279,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> st0, st1, asA, asB, evcount;
   DBuf<unsigned long long> best1, best2;
   DBuf<ReactSet> rs_dev;
+  DBuf<int> conn_start, conn_partner; DBuf<unsigned int> conn_mask;
   Box<R> box{}; BoxD boxd{};
   bool device_ready = false;
   // per-kernel HIP-event samples of the timed region (option time_pair_kernel = N: every N-th step)
@@ -288,6 +313,8 @@ template <typename R> struct CtxT : Ctx {
       box.nc[d] = cells ? nc[d] : 0;
       box.cell_inv[d] = (R)((cells ? nc[d] : 1) / L[d]);
       boxd.L[d] = L[d]; boxd.invL[d] = 1.0 / L[d];
+      box.qs[d] = boxd.qs[d] = q_scale(d); box.qh[d] = boxd.qh[d] = 0.5 * L[d];
+      box.qsf[d] = (R)q_scale(d); box.qinvf[d] = (R)(1.0 / q_scale(d));
     }
     box.ncell = cells ? nc[0] * nc[1] * nc[2] : 1;
     box.zghost = 0; box.z0g = 0; box.nzg = cells ? nc[2] : 1; box.shz_lo = 0; box.shz_hi = 0;
@@ -301,8 +328,8 @@ template <typename R> struct CtxT : Ctx {
       lower = (rk + P - 1) % P; upper = (rk + 1) % P;
       box.zghost = 1; box.z0g = z0; box.nzg = nzg; box.nc[2] = ncz + 2;
       box.ncell = nc[0] * nc[1] * (ncz + 2);
-      box.shz_lo = (R)(z0 == 0 ? -L[2] : 0.0);
-      box.shz_hi = (R)(z0 + ncz == nzg ? L[2] : 0.0);
+      box.shz_lo = enc_shift(z0 == 0 ? -1.0 : 0.0, 2);
+      box.shz_hi = enc_shift(z0 + ncz == nzg ? 1.0 : 0.0, 2);
     }
   }
 
@@ -480,16 +507,25 @@ template <typename R> struct CtxT : Ctx {
         int gz = (int)std::floor(z * nzg / L[2]); gz = std::min(std::max(gz, 0), nzg - 1);
         if (gz < z0 || gz >= z0 + ncz) continue;
         if (k >= cap - G) throw ChemError(CHEM_ENOSPC, "domain decomposition: slab holds more particles than the allocated capacity");
-        hx[k].x = (R)pos0[3 * t]; hx[k].y = (R)pos0[3 * t + 1]; hx[k].z = (R)z; hx[k].w = (R)top.type[t];
+        // (x and y are folded by the first binning pass in the fp64 build; the fixed-point encoding wants them in the box now)
+        const double fx_ = kFixed ? fold_coord(pos0[3 * t], L[0]) : pos0[3 * t], fy_ = kFixed ? fold_coord(pos0[3 * t + 1], L[1]) : pos0[3 * t + 1];
+        hx[k].x = enc_pos(fx_, 0); hx[k].y = enc_pos(fy_, 1); hx[k].z = enc_pos(z, 2); hx[k].w = (R)top.type[t];
+        if (kFixed) { hi[k].x = (int)std::llrint((pos0[3 * t] - fx_) / L[0]); hi[k].y = (int)std::llrint((pos0[3 * t + 1] - fy_) / L[1]); }
         hv[k].x = (R)vel0[3 * t]; hv[k].y = (R)vel0[3 * t + 1]; hv[k].z = (R)vel0[3 * t + 2]; hv[k].w = (R)top.mass[t];
-        ht[k] = t; hi[k] = make_int4(0, 0, (int)s, 0);
+        ht[k] = t; hi[k].z = (int)s;
         ++k;
       }
       n = k - G;
     } else {
       hx.resize(n); hv.resize(n); ht.resize(n); hi.assign(n, make_int4(0, 0, 0, 0));
       for (int t = 0; t < n; ++t) {
-        hx[t].x = (R)pos0[3 * t]; hx[t].y = (R)pos0[3 * t + 1]; hx[t].z = (R)pos0[3 * t + 2]; hx[t].w = (R)top.type[t];
+        if constexpr (kFixed) {   // folded on the host, images counted (the fp64 build leaves that to the first binning pass)
+          for (int d = 0; d < 3; ++d) {
+            const double x = pos0[3 * t + d], xf = fold_coord(x, L[d]);
+            (&hx[t].x)[d] = enc_pos(xf, d); (&hi[t].x)[d] = (int)std::llrint((x - xf) / L[d]);
+          }
+        } else { hx[t].x = (R)pos0[3 * t]; hx[t].y = (R)pos0[3 * t + 1]; hx[t].z = (R)pos0[3 * t + 2]; }
+        hx[t].w = (R)top.type[t];
         hv[t].x = (R)vel0[3 * t]; hv[t].y = (R)vel0[3 * t + 1]; hv[t].z = (R)vel0[3 * t + 2]; hv[t].w = (R)top.mass[t];
         ht[t] = t;
       }
@@ -1086,11 +1122,11 @@ template <typename R> struct CtxT : Ctx {
     // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
     const R cap = (cap_force > 0 && (with_lang || !lang)) ? (R)cap_force : (R)0;
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale());
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale());
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap);
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale());
   }
 
   void check_flags() {
@@ -1319,6 +1355,7 @@ template <typename R> struct CtxT : Ctx {
       r.type_1 = d.type_1; r.type_2 = d.type_2; r.delta_1 = d.delta_1; r.delta_2 = d.delta_2;
       r.min1 = d.min_state_1; r.max1 = d.max_state_1; r.min2 = d.min_state_2; r.max2 = d.max_state_2;
       r.intramolecular = d.intramolecular; r.intraresidual = d.intraresidual; r.active = d.active;
+      r.restricted = (restricted_mask >> q) & 1u;
       r.cut2 = d.cutoff * d.cutoff; r.mincut2 = d.min_cutoff * d.min_cutoff; r.prob = d.rate * dt * (double)interval;
       ras.r[q] = ReactApply{d.delta_1, d.delta_2, d.new_type_1, d.new_type_2, d.new_mass_1, d.new_mass_2};
     }
@@ -1330,18 +1367,32 @@ template <typename R> struct CtxT : Ctx {
     // would migrate particles away from their forces.  Tiles: scan the staged stencils of the last
     // rebuild (see k_react_scan_tiles).  Per-cell / brute-force lists: the int32 list is always current.
     Candidate* cdst = dd_on ? cand_loc.p : cand.p;
+    if (restrict_dirty) {      // per-tag CSR of the allowed partners (both directions), built on the host: the map is set-up data
+      std::vector<int> hs((size_t)nglob + 1, 0), hp; std::vector<unsigned int> hm;
+      for (auto& kv : restrict_map) { hs[kv.first.first + 1]++; hs[kv.first.second + 1]++; }
+      for (int t = 0; t < nglob; ++t) hs[t + 1] += hs[t];
+      hp.resize(hs[nglob] ? hs[nglob] : 1); hm.resize(hp.size());
+      std::vector<int> cur(hs.begin(), hs.end() - 1);
+      for (auto& kv : restrict_map) {
+        hp[cur[kv.first.first]] = kv.first.second; hm[cur[kv.first.first]++] = kv.second;
+        hp[cur[kv.first.second]] = kv.first.first; hm[cur[kv.first.second]++] = kv.second;
+      }
+      conn_start.upload(hs, stream); conn_partner.upload(hp, stream); conn_mask.upload(hm, stream);
+      restrict_dirty = false;
+    }
+    const ConnTable conn{restricted_mask ? conn_start.p : nullptr, conn_partner.p, conn_mask.p};
     if (use_tiles) {
       const int region_cap = std::max(1, cand_cap / std::max(ntiles, 1));
       tile_cnt.alloc(ntiles + 1); tile_off.alloc(ntiles + 1);
       hipLaunchKernelGGL((k_react_scan_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, state.p,
                          res_id.p, mol_id.p, boxd, rs_dev.p, evout.p, region_cap, tile_cnt.p, ctl.p, (R)(0.5 * skin_eff()),
-                         has_excl ? (const int*)excl_start.p : (const int*)nullptr, (const int*)excl_list.p);
+                         has_excl ? (const int*)excl_start.p : (const int*)nullptr, (const int*)excl_list.p, conn);
       hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, stream, ntiles, tile_cnt.p, tile_off.p, ctl.p);
       hipLaunchKernelGGL(k_cand_gather, dim3(std::min(ntiles, 2048)), dim3(256), 0, stream, ntiles, evout.p, region_cap, tile_cnt.p, tile_off.p, cdst, cand_cap, ctl.p);
     } else {
       HIPCHK(hipMemsetAsync(&ctl.p->cand_count, 0, sizeof(int), stream));
       hipLaunchKernelGGL(k_react_scan<R>, dim3(cdiv((long long)n * 8, 256)), dim3(256), 0, stream, G, n, x4.p, tag.p, nlist.p, nn.p, S, state.p,
-                         res_id.p, mol_id.p, boxd, rs_dev.p, cdst, cand_cap, ctl.p);
+                         res_id.p, mol_id.p, boxd, rs_dev.p, cdst, cand_cap, ctl.p, conn);
     }
     DevCtl h = read_ctl();
     trc.lap("scan");
@@ -1697,6 +1748,7 @@ template <typename R> struct CtxT : Ctx {
     StateRec* rec = reinterpret_cast<StateRec*>(loc.data());
     for (int i = 0; i < n; ++i) {
       StateRec r{ht[i], 0, {(double)hv[i].x, (double)hv[i].y, (double)hv[i].z}};
+      if (src == x4.p) { r.v[0] = dec_pos(hv[i].x, 0); r.v[1] = dec_pos(hv[i].y, 1); r.v[2] = dec_pos(hv[i].z, 2); }
       if (what == CHEM_STATE_POS) { for (int k = 0; k < 3; ++k) { double s = std::floor(r.v[k] / L[k]); r.v[k] -= s * L[k]; if (r.v[k] >= L[k]) r.v[k] -= L[k]; } }
       else if (what == CHEM_STATE_POS_UNFOLDED) { r.v[0] += hi[i].x * L[0]; r.v[1] += hi[i].y * L[1]; r.v[2] += hi[i].z * L[2]; }
       else if (what == CHEM_STATE_IMAGE) { r.v[0] = hi[i].x; r.v[1] = hi[i].y; r.v[2] = hi[i].z; }
@@ -2160,6 +2212,22 @@ int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* r) {
   REQUIRE(r->new_mass > 0, CHEM_EINVAL, "neighbour_change: new_mass");
   REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "neighbour property changes on the decomposed path");
   c.nb_rules.push_back(*r); c.pair_dirty = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_reaction_restrict(chem_ctx* ctx, int reaction, int64_t n, const int64_t* p) {
+  API_BEGIN
+  Ctx& c = CTX;
+  REQUIRE(reaction >= 0 && reaction < (int)c.reactions.size() && reaction < 32, CHEM_EINVAL, "reaction_restrict: reaction index");
+  REQUIRE(n >= 0 && (n == 0 || p), CHEM_EINVAL, "reaction_restrict: pairs");
+  REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "restricted reactions on the decomposed path");
+  for (int64_t k = 0; k < n; ++k) {
+    const int a = c.top.tag_of(p[2 * k]), b = c.top.tag_of(p[2 * k + 1]);
+    REQUIRE(a >= 0 && b >= 0 && a != b, CHEM_EINVAL, "reaction_restrict: unknown id or self pair");
+    c.restrict_map[{std::min(a, b), std::max(a, b)}] |= 1u << reaction;
+  }
+  c.restricted_mask |= 1u << reaction; c.restrict_dirty = true;
   return 0;
   API_END(ctx)
 }

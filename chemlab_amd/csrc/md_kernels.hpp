@@ -79,7 +79,86 @@ template <typename R> struct Box {
   int zghost;      // 0: z periodic in-kernel, 1: ghost layers
   int z0g, nzg;    // first own global layer, global layer count
   R shz_lo, shz_hi;  // shift to apply to the lower / upper ghost layer (+-Lz across the periodic boundary)
+  // Fixed-point positions (R = float only, see "position codec" below): q = rint((x - L/2) / qs), qs = L / 2^31
+  double qs[3], qh[3];     // scale and half box edge (fp64: exact decoding)
+  R qsf[3], qinvf[3];      // scale and 1 / scale in R (staging, integrator)
 };
+
+// ---- position codec ------------------------------------------------------------------------------------------------
+// fp64 build: x4 = (x, y, z, type) in real coordinates.
+// fp32 build: x4.xyz carry the BIT PATTERNS of int32 fixed-point coordinates  q = rint((x - L/2) / qs),  qs = L / 2^31
+//   (resolution 5e-8 at L = 108, uniform over the box; the box is q in [-2^30, 2^30), int32 leaves half a box of headroom
+//   on either side for the drift between two rebuilds; one box length is 2^31, i.e. the periodic shift is a wrap of the
+//   32-bit arithmetic).  x4.w stays the type as a float.  Why: an absolute fp32 coordinate at x ~ 100 has an ulp of 7.6e-6,
+//   and that -- not the fp32 pair arithmetic -- set the force error at the headline size (2e-4 of the largest force at
+//   L = 107.7; SURVEY App. E asks 1e-5).  The kernels that matter stage TILE-LOCAL coordinates: (q + shift - q_ref) is
+//   exact in integers and only the small result (|u| <= 7.1) is rounded to fp32.  The integrator adds rint(dt v / qs).
+constexpr int kQHalf = 1 << 30;
+__device__ __forceinline__ int qbits(float v) { return __float_as_int(v); }
+__device__ __forceinline__ float qmake(int q) { return __int_as_float(q); }
+struct D3 { double x, y, z; };
+// exact real coordinates
+__device__ __forceinline__ D3 pos_real(const float4& p, const double* qs, const double* qh) {
+  return {(double)qbits(p.x) * qs[0] + qh[0], (double)qbits(p.y) * qs[1] + qh[1], (double)qbits(p.z) * qs[2] + qh[2]};
+}
+__device__ __forceinline__ D3 pos_real(const double4& p, const double*, const double*) { return {p.x, p.y, p.z}; }
+// real coordinates in R (fp32 build: absolute fp32, for the paths where that is enough: fall-back kernels, sub-bin keys)
+__device__ __forceinline__ float4 pos_abs(const float4& p, const Box<float>& b) {
+  return make_float4((float)((double)qbits(p.x) * b.qs[0] + b.qh[0]), (float)((double)qbits(p.y) * b.qs[1] + b.qh[1]),
+                     (float)((double)qbits(p.z) * b.qs[2] + b.qh[2]), p.w);
+}
+__device__ __forceinline__ double4 pos_abs(const double4& p, const Box<double>&) { return p; }
+// cell index along axis d (nc cells), the box being [0, L): exact integer arithmetic in the fp32 build
+__device__ __forceinline__ int pos_cell(float c, int d, int nc, const Box<float>&) {
+  const long long o = (long long)qbits(c) + kQHalf;
+  int cc = (int)((o * nc) >> 31);
+  return cc >= nc ? nc - 1 : (cc < 0 ? 0 : cc);
+}
+__device__ __forceinline__ int pos_cell(double c, int d, int nc, const Box<double>& b) {
+  int cc = (int)(c * ((double)nc * b.invL[d]));
+  return cc >= nc ? nc - 1 : (cc < 0 ? 0 : cc);
+}
+// fold coordinate d into the box, counting the images; returns true when the value changed
+__device__ __forceinline__ bool pos_fold(float& c, int& img, int d, const Box<float>&) {
+  int q = qbits(c);
+  if (q >= kQHalf) { q = (int)((unsigned)q + 0x80000000u); img += 1; c = qmake(q); return true; }
+  if (q < -kQHalf) { q = (int)((unsigned)q + 0x80000000u); img -= 1; c = qmake(q); return true; }
+  return false;
+}
+__device__ __forceinline__ bool pos_fold(double& c, int& img, int d, const Box<double>& box) {
+  bool moved = false;
+  double s_ = floor(c * box.invL[d]);
+  if (s_ != 0.0) { c -= s_ * box.L[d]; img += (int)s_; moved = true; }
+  if (c >= box.L[d]) { c -= box.L[d]; img += 1; moved = true; }
+  if (c < 0.0) { c += box.L[d]; img -= 1; moved = true; }
+  return moved;
+}
+// x + dx (integrator drift)
+__device__ __forceinline__ float pos_add(float c, float dx, float qinv) { return qmake(qbits(c) + __float2int_rn(dx * qinv)); }
+__device__ __forceinline__ double pos_add(double c, double dx, double) { return c + dx; }
+// a - b in real units (displacement since a snapshot)
+__device__ __forceinline__ float pos_diff(float a, float b, float qs) { return (float)(qbits(a) - qbits(b)) * qs; }
+__device__ __forceinline__ double pos_diff(double a, double b, double) { return a - b; }
+// encoding of a real coordinate (descriptor tables: reference point of a tile) and of a periodic shift of k box lengths
+__device__ __forceinline__ float pos_enc(double x, int d, const Box<float>& b) { return qmake((int)(long long)rint((x - b.qh[d]) / b.qs[d])); }
+__device__ __forceinline__ double pos_enc(double x, int d, const Box<double>&) { return x; }
+__device__ __forceinline__ float pos_shift(int k, int d, const Box<float>&) { return qmake((int)((unsigned)k << 31)); }     // +-1 box = 2^31: the same wrap
+__device__ __forceinline__ double pos_shift(int k, int d, const Box<double>& b) { return (double)k * b.L[d]; }
+// tile-local coordinate (p + shift) - ref as a float / double: integers in the fp32 build, only the small result is rounded
+__device__ __forceinline__ float pos_local(float p, float shift, float ref, float qs) {
+  return (float)(int)((unsigned)qbits(p) + (unsigned)qbits(shift) - (unsigned)qbits(ref)) * qs;
+}
+__device__ __forceinline__ double pos_local(double p, double shift, double ref, double) { return (p + shift) - ref; }
+// minimum-image difference a - b along axis d (fall-back kernels that gather positions through global memory)
+__device__ __forceinline__ float pos_delta(float a, float b, int d, const Box<float>& box) {
+  int dq = (int)((unsigned)qbits(a) - (unsigned)qbits(b));
+  if (dq >= kQHalf) dq = (int)((unsigned)dq + 0x80000000u); else if (dq < -kQHalf) dq = (int)((unsigned)dq + 0x80000000u);
+  return (float)dq * box.qsf[d];
+}
+__device__ __forceinline__ double pos_delta(double a, double b, int d, const Box<double>& box) {
+  const double x = a - b;
+  return x - box.L[d] * rint(x * box.invL[d]);
+}
 
 // Non-bonded parameters of one type pair, pre-multiplied (gromacs_topology.py:715-721,
 // doc/topology.rst:12-14).  PairCore is the only thing the LJ fast path touches (one 16-byte
@@ -125,11 +204,12 @@ __device__ __forceinline__ void langevin_force(const LangevinP<R>& lp, int tag, 
 // (thermalize at aftCalcF) and, when mode has no drift..., store f_total back.
 // x0 != nullptr: rebuild criterion "displacement" (max |x - x_at_last_build|^2); nullptr: the
 // reference's accumulated per-step maxima (max |dt v|^2 of this step)
+template <typename R> struct PosScale { R s[3], inv[3]; };   // fixed-point scale of the positions (fp32 build; unused in fp64)
 template <typename R, int MODE, bool LANG, bool STOREF>
 __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
                                                     R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax,
-                                                    const Vec4<R>* __restrict__ x0, R cap) {
+                                                    const Vec4<R>* __restrict__ x0, R cap, PosScale<R> ps) {
   // kIntPerBlock particles per 256-thread block: every thread owns kIntPerBlock/256 particles and issues
   // all their loads before the first dependent instruction (more bytes in flight per wave for this
   // purely HBM-bound kernel); the arithmetic per particle is unchanged
@@ -172,9 +252,9 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
       v.x += hm * f.x; v.y += hm * f.y; v.z += hm * f.z;
       Vec4<R> x = xx[u];
       R dx = dt * v.x, dy = dt * v.y, dz = dt * v.z;
-      x.x += dx; x.y += dy; x.z += dz;
+      x.x = pos_add(x.x, dx, ps.inv[0]); x.y = pos_add(x.y, dy, ps.inv[1]); x.z = pos_add(x.z, dz, ps.inv[2]);
       x4[i] = x;
-      if (x0) { const Vec4<R> o = x0[i]; dx = x.x - o.x; dy = x.y - o.y; dz = x.z - o.z; }
+      if (x0) { const Vec4<R> o = x0[i]; dx = pos_diff(x.x, o.x, ps.s[0]); dy = pos_diff(x.y, o.y, ps.s[1]); dz = pos_diff(x.z, o.z, ps.s[2]); }
       const R dd = dx * dx + dy * dy + dz * dz;
       d2 = dd > d2 ? dd : d2;
     }
@@ -289,14 +369,9 @@ __device__ __forceinline__ void dev_bin(int i0, int n, Vec4<R>* x4, const Vec4<R
         bool moved = false;   // folded back into the box: only then position and image counters are written back
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-          R s_ = floor_r(p[d] * box.invL[d]);
-          if (s_ != (R)0) { p[d] -= s_ * box.L[d]; ip[d] += (int)s_; moved = true; }
-          if (p[d] >= box.L[d]) { p[d] -= box.L[d]; ip[d] += 1; moved = true; }
-          if (p[d] < (R)0) { p[d] += box.L[d]; ip[d] -= 1; moved = true; }
-          int cc = (int)(p[d] * box.cell_inv[d]);
-          int ncd = (d == 2 && box.zghost) ? box.nzg : (box.nc[d] > 0 ? box.nc[d] : 1);
-          cc = cc >= ncd ? ncd - 1 : (cc < 0 ? 0 : cc);
-          c[d] = cc;
+          moved |= pos_fold(p[d], ip[d], d, box);
+          const int ncd = (d == 2 && box.zghost) ? box.nzg : (box.nc[d] > 0 ? box.nc[d] : 1);
+          c[d] = pos_cell(p[d], d, ncd, box);
         }
         int dir = 0;   // 0 stays, -1 leaves downwards, +1 upwards
         if (box.zghost) {
@@ -466,7 +541,8 @@ constexpr int NSUB = 4;
 // y/z halves make neighbouring lanes of the force kernel (consecutive home particles) spatial neighbours, whose
 // slot-sorted lists then read nearby LDS slots in the same instruction (fewer bank conflicts, more broadcasts)
 template <typename R>
-__device__ __forceinline__ int sort_key(const Vec4<R>& x, int c, const Box<R>& box, int tg) {
+__device__ __forceinline__ int sort_key(const Vec4<R>& xq, int c, const Box<R>& box, int tg) {
+  const Vec4<R> x = pos_abs(xq, box);   // (slices and halves only order the cell and prune windows: absolute fp32 is enough)
   const int nx = box.nc[0] > 0 ? box.nc[0] : 1, ny = box.nc[1] > 0 ? box.nc[1] : 1, nz = box.nc[2] > 0 ? box.nc[2] : 1;
   const int cx = c % nx, cy = (c / nx) % ny;
   const R clx = box.L[0] / (R)nx, cly = box.L[1] / (R)ny;
@@ -760,7 +836,7 @@ __global__ __launch_bounds__(256) void k_nlist_cells(int n, const Vec4<R>* __res
         for (int t = l; t < cnt; t += 64) {
           const int dst = o0 + t;
           if (dst >= 0 && dst < CAP) {
-            Vec4<R> p = x4[s0 + t];
+            Vec4<R> p = pos_abs(x4[s0 + t], box);
             p.x += sh0; p.y += sh1; p.z += sh2; p.w = idx_as_real(s0 + t, (R)0);
             sx[dst] = p;
           }
@@ -769,7 +845,7 @@ __global__ __launch_bounds__(256) void k_nlist_cells(int n, const Vec4<R>* __res
       __syncthreads();
       const bool last = base + CAP >= total_all;
       for (int p = hs + w; p < he; p += 4) {
-        const Vec4<R> xi = x4[p];
+        const Vec4<R> xi = pos_abs(x4[p], box);
         int e0 = 0, e1 = 0;
         if (has_excl) { int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
         int cnt = 0;
@@ -825,9 +901,7 @@ __global__ __launch_bounds__(256) void k_nlist_brute(int n, const Vec4<R>* __res
     bool ok = j < n && j != p;
     if (ok) {
       const Vec4<R> xj = x4[j];
-      const R dx = minimg1<R>(xi.x - xj.x, box.L[0], box.invL[0]);
-      const R dy = minimg1<R>(xi.y - xj.y, box.L[1], box.invL[1]);
-      const R dz = minimg1<R>(xi.z - xj.z, box.L[2], box.invL[2]);
+      const R dx = pos_delta(xi.x, xj.x, 0, box), dy = pos_delta(xi.y, xj.y, 1, box), dz = pos_delta(xi.z, xj.z, 2, box);
       ok = dx * dx + dy * dy + dz * dz <= rl2;
       if (ok && e1 > e0) {
         const int tj = tag[j];
@@ -904,9 +978,7 @@ __global__ __launch_bounds__(256) void k_pair_force(int n, const Vec4<R>* __rest
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const Vec4<R> xj = xs[u];
-        const R dx = minimg1<R>(xi.x - xj.x, box.L[0], box.invL[0]);
-        const R dy = minimg1<R>(xi.y - xj.y, box.L[1], box.invL[1]);
-        const R dz = minimg1<R>(xi.z - xj.z, box.L[2], box.invL[2]);
+        const R dx = pos_delta(xi.x, xj.x, 0, box), dy = pos_delta(xi.y, xj.y, 1, box), dz = pos_delta(xi.z, xj.z, 2, box);
         R r2 = dx * dx + dy * dy + dz * dz;
         r2 = (k + u < cnt) ? r2 : (R)1e30;     // padding entries (self index) never interact
         const int pidx = pbase + (int)xj.w;
@@ -974,8 +1046,13 @@ template <typename R> struct TileLDS {
   // list build only: x sub-bin prefixes of every stencil cell (cell_sub, see dev_sort_gather; -1 = unknown),
   // staged coordinates of the lower corner of stencil cell (0,0,0), cell edges, sub-bins per unit length
   int cellsub[NROW][SX];
+  // org: reference point of the staged coordinates = lower corner of stencil cell (0,0,0) + kRefCells cell edges (the centre of
+  // a full 5x5x5 stencil: |staged coordinate| <= 2.5 edges + skin/2, the smallest magnitudes fp32 can be given), in the
+  // encoding of the position arrays (pos_enc); clen: cell edges; subinv: sub-bins per unit length; qs: fixed-point scale
   R org[3], clen[3], subinv, pad_;
+  R qs[3], pad2_;
 };
+constexpr float kRefCells = 2.5f;
 
 // NOTE: the pointer must stay a plain local derived from the extern array (no integer
 // round-trip, never stored in memory) so that the compiler keeps it in the LDS address space
@@ -1004,10 +1081,10 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
     if (ry < hy + 2 && rz < hz + 2 && k < hx + 2) {
       int ox = cx0 - 1 + k, oy = cy0 - 1 + ry, oz = cz0 - 1 + rz;
       R shy = 0, shz = 0;
-      if (ox < 0) { ox += nx; shx = -box.L[0]; } else if (ox >= nx) { ox -= nx; shx = box.L[0]; }
-      if (oy < 0) { oy += ny; shy = -box.L[1]; } else if (oy >= ny) { oy -= ny; shy = box.L[1]; }
+      if (ox < 0) { ox += nx; shx = pos_shift(-1, 0, box); } else if (ox >= nx) { ox -= nx; shx = pos_shift(1, 0, box); }
+      if (oy < 0) { oy += ny; shy = pos_shift(-1, 1, box); } else if (oy >= ny) { oy -= ny; shy = pos_shift(1, 1, box); }
       if (zg) { shz = oz == 0 ? box.shz_lo : (oz == nz - 1 ? box.shz_hi : (R)0); }
-      else if (oz < 0) { oz += nz; shz = -box.L[2]; } else if (oz >= nz) { oz -= nz; shz = box.L[2]; }
+      else if (oz < 0) { oz += nz; shz = pos_shift(-1, 2, box); } else if (oz >= nz) { oz -= nz; shz = pos_shift(1, 2, box); }
       const int oc = (oz * ny + oy) * nx + ox;
       g = cell_start[oc]; cnt = cell_start[oc + 1] - g;
       sub = cell_sub ? cell_sub[oc] : -1;
@@ -1057,11 +1134,12 @@ __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int ti
     // geometry of the staged image (list build, x-window of a row).  In z-ghost mode layer l of the slab is the
     // global layer z0g + l - 1; the staged z of the ghost layers carries shz_lo / shz_hi, which continues the
     // same affine map across the periodic boundary.
-    const R clx = box.L[0] / (R)nx, cly = box.L[1] / (R)ny, clz = box.L[2] / (R)(zg ? box.nzg : nz);
-    T.clen[0] = clx; T.clen[1] = cly; T.clen[2] = clz;
-    T.org[0] = (R)(cx0 - 1) * clx; T.org[1] = (R)(cy0 - 1) * cly;
-    T.org[2] = (R)(zg ? box.z0g + cz0 - 2 : cz0 - 1) * clz;
-    T.subinv = (R)NSUB / clx; T.pad_ = 0;
+    const double clx = 2.0 * box.qh[0] / nx, cly = 2.0 * box.qh[1] / ny, clz = 2.0 * box.qh[2] / (zg ? box.nzg : nz);   // (qh = L / 2 in fp64)
+    T.clen[0] = (R)clx; T.clen[1] = (R)cly; T.clen[2] = (R)clz;
+    T.org[0] = pos_enc(((double)(cx0 - 1) + kRefCells) * clx, 0, box); T.org[1] = pos_enc(((double)(cy0 - 1) + kRefCells) * cly, 1, box);
+    T.org[2] = pos_enc(((double)(zg ? box.z0g + cz0 - 2 : cz0 - 1) + kRefCells) * clz, 2, box);
+    T.subinv = (R)((double)NSUB / clx); T.pad_ = 0;
+    T.qs[0] = box.qsf[0]; T.qs[1] = box.qsf[1]; T.qs[2] = box.qsf[2]; T.pad2_ = 0;
   }
   __syncthreads();
 }
@@ -1121,7 +1199,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
         const int dst = o0 + e;
         if (dst < CAP) {
           Vec4<R> p = x4[g];
-          p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
+          p.x = pos_local(p.x, T.cellshx[r][k], T.org[0], T.qs[0]); p.y = pos_local(p.y, T.rowshy[r], T.org[1], T.qs[1]); p.z = pos_local(p.z, T.rowshz[r], T.org[2], T.qs[2]);
           if (wmode) p.w = idx_as_real((g << 5) | (int)p.w, (R)0);
           slot_store<R, D3>(sx, CAP, dst, p);
         }
@@ -1159,7 +1237,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
         const int dst = T.rowoff[r] + l + 64 * c;
         if (dst < CAP) {
           Vec4<R> p = pv[rr][c];
-          p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
+          p.x = pos_local(p.x, T.cellshx[r][k], T.org[0], T.qs[0]); p.y = pos_local(p.y, T.rowshy[r], T.org[1], T.qs[1]); p.z = pos_local(p.z, T.rowshz[r], T.org[2], T.qs[2]);
           if (wmode) p.w = idx_as_real((pg[rr][c] << 5) | (int)p.w, (R)0);
           slot_store<R, D3>(sx, CAP, dst, p);
         }
@@ -1177,7 +1255,7 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
       const int dst = o0 + e;
       if (dst < CAP) {
         Vec4<R> p = x4[g];
-        p.x += T.cellshx[r][k]; p.y += T.rowshy[r]; p.z += T.rowshz[r];
+        p.x = pos_local(p.x, T.cellshx[r][k], T.org[0], T.qs[0]); p.y = pos_local(p.y, T.rowshy[r], T.org[1], T.qs[1]); p.z = pos_local(p.z, T.rowshz[r], T.org[2], T.qs[2]);
         if (wmode) p.w = idx_as_real((g << 5) | (int)p.w, (R)0);
         slot_store<R, D3>(sx, CAP, dst, p);
       }
@@ -1268,7 +1346,8 @@ __device__ __forceinline__ void list_stage_f32(TileLDS<RS>& T, unsigned char* ld
         if (dst < CAP) {
           const Vec4<RS> p = x4[g];
           CHEM_LDS float* grp = img + (dst >> 2) * kGrpF + (dst & 3);
-          const float u = (float)((p.x + T.cellshx[r][k]) - T.org[0]), v = (float)((p.y + T.rowshy[r]) - T.org[1]), w_ = (float)((p.z + T.rowshz[r]) - T.org[2]);
+          const float u = (float)pos_local(p.x, T.cellshx[r][k], T.org[0], T.qs[0]), v = (float)pos_local(p.y, T.rowshy[r], T.org[1], T.qs[1]),
+                      w_ = (float)pos_local(p.z, T.rowshz[r], T.org[2], T.qs[2]);
           grp[0] = u; grp[4] = v; grp[8] = w_; grp[12] = fmaf(u, u, fmaf(v, v, w_ * w_));   // (explicit: the same rounding in every kernel this is inlined into)
           tj = (int)p.w & 15;
         }
@@ -1399,13 +1478,13 @@ __device__ __forceinline__ void dev_nlist_tile(const TileLDS<R>& T, Vec4<R>* con
         const int r = (lz + dz) * SY + (ly + dy);
         // (everything is recomputed per row from the LDS tables: keeping it live across the row loop spills)
         const R weps = T.clen[0] * (R)2e-4;
-        const R ylo = T.org[1] + (R)(ly + 1) * T.clen[1], zlo = T.org[2] + (R)(lz + 1) * T.clen[2];
+        const R ylo = ((R)(ly + 1) - (R)kRefCells) * T.clen[1], zlo = ((R)(lz + 1) - (R)kRefCells) * T.clen[2];   // (staged coordinates are relative to T.org)
         R ddy = dy == 0 ? xi.y - ylo - weps : (dy == 2 ? ylo + T.clen[1] - xi.y - weps : (R)0);
         R ddz = dz == 0 ? xi.z - zlo - weps : (dz == 2 ? zlo + T.clen[2] - xi.z - weps : (R)0);
         ddy = ddy > 0 ? ddy : (R)0; ddz = ddz > 0 ? ddz : (R)0;
         const R w2 = rl2 - ddy * ddy - ddz * ddz;
         if (w2 < (R)0) continue;
-        const R ws = (sqrt_r(w2) + weps) * T.subinv, sxi = (xi.x - T.org[0]) * T.subinv;
+        const R ws = (sqrt_r(w2) + weps) * T.subinv, sxi = (xi.x + (R)kRefCells * T.clen[0]) * T.subinv;
         int f_lo = (int)(sxi - ws), f_hi = (int)(sxi + ws);     // truncation == floor where it matters (clamped below at >= 0)
         f_lo = f_lo > lx * NSUB ? f_lo : lx * NSUB;
         f_hi = f_hi < (lx + 3) * NSUB - 1 ? f_hi : (lx + 3) * NSUB - 1;
@@ -1514,8 +1593,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
           const int g = rtag[excl_list[e0 + k]];
           if (g >= 0) {
             const Vec4<RS> xg = x4[g];
-            int cx = (int)(xg.x * bx->cell_inv[0]), cy = (int)(xg.y * bx->cell_inv[1]), cz = (int)(xg.z * bx->cell_inv[2]);
-            cx = cx >= nx ? nx - 1 : (cx < 0 ? 0 : cx); cy = cy >= ny ? ny - 1 : (cy < 0 ? 0 : cy); cz = cz >= nz ? nz - 1 : (cz < 0 ? 0 : cz);
+            const int cx = pos_cell(xg.x, 0, nx, *bx), cy = pos_cell(xg.y, 1, ny, *bx), cz = pos_cell(xg.z, 2, nz, *bx);   // (the binning arithmetic on the same bits)
             int kx = cx - (org & 1023) + 1, ky = cy - ((org >> 10) & 1023) + 1, kz = cz - (org >> 20) + 1;
             kx += kx < 0 ? nx : 0; kx -= kx >= nx ? nx : 0;
             ky += ky < 0 ? ny : 0; ky -= ky >= ny ? ny : 0;
@@ -1549,10 +1627,10 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
     // slices only prune, the distance test decides membership).
     const float clen0 = (float)T.clen[0], clen1 = (float)T.clen[1], clen2 = (float)T.clen[2], subinv = (float)T.subinv;
     const float weps = clen0 * 2e-4f;
-    const float ylo = (float)(ly + 1) * clen1, zlo = (float)(lz + 1) * clen2;
+    const float ylo = ((float)(ly + 1) - kRefCells) * clen1, zlo = ((float)(lz + 1) - kRefCells) * clen2;   // (image coordinates are relative to T.org)
     const float dylo = fmaxf(xiy - ylo - weps, 0.f), dyhi = fmaxf(ylo + clen1 - xiy - weps, 0.f);
     const float dzlo = fmaxf(xiz - zlo - weps, 0.f), dzhi = fmaxf(zlo + clen2 - xiz - weps, 0.f);
-    const float sxi = xix * subinv;
+    const float sxi = (xix + kRefCells * clen0) * subinv;
     const int fmin = lx * NSUB, fmax = (lx + 3) * NSUB - 1;
     auto window = [&](int dzy, int& a, int& b) {
       const int dz = dzy / 3, dy = dzy - 3 * dz;
@@ -1919,18 +1997,25 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
 struct BondedEntry { int t0, t1, t2, meta; };   // tuple tags in order (self included); meta = slot | mypos<<28; quadruples use a 2nd entry for t3
 struct BondedParam { int kind, list, arity, pad; double p[CHEM_MAX_POT_PARAMS]; };
 
-struct D3 { double x, y, z; };
 __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 __device__ __forceinline__ D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
 __device__ __forceinline__ double dot3(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 __device__ __forceinline__ D3 cross3(D3 a, D3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 
-struct BoxD { double L[3], invL[3]; };
+struct BoxD { double L[3], invL[3]; double qs[3], qh[3]; };   // qs, qh: fixed-point decoding of the fp32 build's positions (Box<R>)
 __device__ __forceinline__ D3 minimgD(const BoxD& b, D3 d) {
   return {d.x - b.L[0] * rint(d.x * b.invL[0]), d.y - b.L[1] * rint(d.y * b.invL[1]), d.z - b.L[2] * rint(d.z * b.invL[2])};
 }
-template <typename R> __device__ __forceinline__ D3 posD(const Vec4<R>& v) { return {(double)v.x, (double)v.y, (double)v.z}; }
+// |d|^2 exactly as the CPU oracle rounds it: three products, two sums, NO fused multiply-add.  (__dmul_rn / __dadd_rn are plain
+// operators in the HIP headers and -ffp-contract=fast fused them; invisible as long as the test positions were fp32 values,
+// whose products are exact in fp64.)
+__device__ __forceinline__ double dist2_unfused(const D3& d) {
+#pragma clang fp contract(off)
+  const double xx = d.x * d.x, yy = d.y * d.y, zz = d.z * d.z;
+  return (xx + yy) + zz;
+}
+template <typename R> __device__ __forceinline__ D3 posD(const Vec4<R>& v, const BoxD& b) { return pos_real(v, b.qs, b.qh); }   // exact in both builds
 
 // bond tables (chem_table_create): rows = (e, f) pairs of all tables back to back, info[h] = (first row, rows, r0, 1/dr)
 struct BTab { const double2* rows; const double4* info; };
@@ -1946,7 +2031,7 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
     if (BONDS_ONLY || bp.arity == 2) {
       // tuple (t0,t1); r_ij = x_t0 - x_t1
       if ((j0 | j1) < 0) { ctl->bonded_missing = 1; return; }
-      const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]);
+      const D3 x0 = posD<R>(x4[j0], box), x1 = posD<R>(x4[j1], box);
       const D3 d = minimgD(box, x0 - x1);
       const double r = sqrt(dot3(d, d));
       double ff = 0;
@@ -1981,7 +2066,7 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
     } else if (BONDS_ONLY) {
     } else if (bp.arity == 3) {
       if ((j0 | j1 | j2) < 0) { ctl->bonded_missing = 1; return; }
-      const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]), x2 = posD<R>(x4[j2]);
+      const D3 x0 = posD<R>(x4[j0], box), x1 = posD<R>(x4[j1], box), x2 = posD<R>(x4[j2], box);
       const D3 r1 = minimgD(box, x0 - x1), r2 = minimgD(box, x2 - x1);
       const double n1 = sqrt(dot3(r1, r1)), n2 = sqrt(dot3(r2, r2));
       double c = dot3(r1, r2) / (n1 * n2);
@@ -2009,7 +2094,7 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
       if (me == 0) f = f + fi; else if (me == 2) f = f + fk; else f = f - (fi + fk);
     } else {
       if ((j0 | j1 | j2 | j3) < 0) { ctl->bonded_missing = 1; return; }
-      const D3 x0 = posD<R>(x4[j0]), x1 = posD<R>(x4[j1]), x2 = posD<R>(x4[j2]), x3 = posD<R>(x4[j3]);
+      const D3 x0 = posD<R>(x4[j0], box), x1 = posD<R>(x4[j1], box), x2 = posD<R>(x4[j2], box), x3 = posD<R>(x4[j3], box);
       const D3 b1 = minimgD(box, x1 - x0), b2 = minimgD(box, x2 - x1), b3 = minimgD(box, x3 - x2);
       const D3 m = cross3(b1, b2), nn = cross3(b2, b3);
       const double m2 = dot3(m, m), n2 = dot3(nn, nn), lb2 = dot3(b2, b2), lb = sqrt(lb2);
@@ -2564,10 +2649,17 @@ __global__ __launch_bounds__(256) void k_scale_v(int i0, int n, Vec4<R>* __restr
 struct ReactionDev {
   int type_1, type_2, delta_1, delta_2;
   int min1, max1, min2, max2;
-  int intramolecular, intraresidual, active, pad;
+  int intramolecular, intraresidual, active, restricted;   // restricted: RestrictReaction -- only pairs of the connection table react
   double cut2, mincut2, prob;
 };
 struct ReactSet { int n; uint64_t seed; uint64_t step; int nearest; ReactionDev r[CHEM_MAX_REACTIONS]; };
+// RestrictReaction.define_connection (reaction_setup.py:115-128): per-tag CSR of the allowed partners, one bit per reaction
+struct ConnTable { const int* start; const int* partner; const unsigned int* mask; };
+__device__ __forceinline__ bool conn_allows(const ConnTable& ct, int ta, int tb, int q) {
+  if (!ct.start) return false;
+  for (int e = ct.start[ta]; e < ct.start[ta + 1]; ++e) if (ct.partner[e] == tb) return (ct.mask[e] >> q) & 1u;
+  return false;
+}
 
 struct Candidate { int a, b, r; unsigned int h; double d2; };  // a: role type_1, b: role type_2 (tags)
 
@@ -2579,7 +2671,7 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
                                                     const int* __restrict__ nlist, const int* __restrict__ nn, int S,
                                                     const int* __restrict__ state, const int* __restrict__ res_id,
                                                     const int* __restrict__ mol_id, BoxD box, const ReactSet* __restrict__ rs_g,
-                                                    Candidate* __restrict__ cand, int cand_cap, DevCtl* ctl) {
+                                                    Candidate* __restrict__ cand, int cand_cap, DevCtl* ctl, ConnTable conn) {
   __shared__ ReactSet rs;
   {
     const int* src = reinterpret_cast<const int*>(rs_g);
@@ -2630,7 +2722,8 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
         // cheap reject before the three by-tag gathers and the fp64 arithmetic: the reaction radii are
         // far inside the list radius (1.2 vs 2.8: 8 % of the neighbours).  Same inputs as the fp64
         // distance below, 1e-3 relative margin >> any rounding difference.
-        const float fx = (float)xi.x - (float)xj.x, fy = (float)xi.y - (float)xj.y, fz = (float)xi.z - (float)xj.z;
+        const D3 pi_ = posD<R>(xi, box), pj_ = posD<R>(xj, box);
+        const float fx = (float)(pi_.x - pj_.x), fy = (float)(pi_.y - pj_.y), fz = (float)(pi_.z - pj_.z);
         const float gx = fx - bLf[0] * rintf(fx * biLf[0]), gy = fy - bLf[1] * rintf(fy * biLf[1]), gz = fz - bLf[2] * rintf(fz * biLf[2]);
         live = gx * gx + gy * gy + gz * gz <= maxcut2f;
       }
@@ -2639,8 +2732,8 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
     double d2 = 0;
     if (__any(live)) {
       if (live) {
-        D3 d = minimgD(box, posD<R>(xi) - posD<R>(xj));
-        d2 = __dadd_rn(__dadd_rn(__dmul_rn(d.x, d.x), __dmul_rn(d.y, d.y)), __dmul_rn(d.z, d.z));
+        D3 d = minimgD(box, posD<R>(xi, box) - posD<R>(xj, box));
+        d2 = dist2_unfused(d);
       }
       for (int q = 0; q < rs.n; ++q) {
         const ReactionDev& R_ = rs.r[q];
@@ -2654,6 +2747,7 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
             if (!R_.intraresidual && ri == rj) hit = false;
             if (!R_.intramolecular && mi == mj) hit = false;
             if (!(d2 >= R_.mincut2 && d2 < R_.cut2)) hit = false;
+            if (hit && R_.restricted && !conn_allows(conn, tgi, tgj, q)) hit = false;
             if (hit) {
               uint32_t rr[4];
               chem_philox::reaction_draw(rs.seed, rs.step, (uint32_t)tgi, (uint32_t)tgj, (uint32_t)q, rr);
@@ -2704,7 +2798,7 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
                                                             const int* __restrict__ res_id, const int* __restrict__ mol_id, BoxD box,
                                                             const ReactSet* __restrict__ rs_g, Candidate* __restrict__ region, int region_cap,
                                                             int* __restrict__ tile_count, DevCtl* ctl, R slack,
-                                                            const int* __restrict__ excl_start, const int* __restrict__ excl_list) {
+                                                            const int* __restrict__ excl_start, const int* __restrict__ excl_list, ConnTable conn) {
   __shared__ TileLDS<R> T;
   __shared__ ReactSet rs;
   __shared__ int s_cnt;
@@ -2766,14 +2860,14 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
       for (int dzy = 0; dzy < 9; ++dzy) {
         const int dz = dzy / 3, dy = dzy - 3 * dz;
         const int r = (lz + dz) * SY + (ly + dy);
-        const R ylo = T.org[1] + (R)(ly + 1) * T.clen[1], zlo = T.org[2] + (R)(lz + 1) * T.clen[2];
+        const R ylo = ((R)(ly + 1) - (R)kRefCells) * T.clen[1], zlo = ((R)(lz + 1) - (R)kRefCells) * T.clen[2];   // (staged coordinates are relative to T.org)
         R ddy = dy == 0 ? xi.y - ylo : (dy == 2 ? ylo + T.clen[1] - xi.y : (R)0);
         R ddz = dz == 0 ? xi.z - zlo : (dz == 2 ? zlo + T.clen[2] - xi.z : (R)0);
         ddy -= slack + weps; ddz -= slack + weps;
         ddy = ddy > 0 ? ddy : (R)0; ddz = ddz > 0 ? ddz : (R)0;
         const R w2 = rmax * rmax - ddy * ddy - ddz * ddz;
         if (w2 < (R)0) continue;
-        const R ws = (sqrt_r(w2) + slack + weps) * T.subinv, sxi = (xi.x - T.org[0]) * T.subinv;
+        const R ws = (sqrt_r(w2) + slack + weps) * T.subinv, sxi = (xi.x + (R)kRefCells * T.clen[0]) * T.subinv;
         int f_lo = (int)(sxi - ws), f_hi = (int)(sxi + ws);
         f_lo = f_lo > lx * NSUB ? f_lo : lx * NSUB;
         f_hi = f_hi < (lx + 3) * NSUB - 1 ? f_hi : (lx + 3) * NSUB - 1;
@@ -2801,8 +2895,8 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
             if (ex) continue;
           }
           const int sj = state[tgj], rj = res_id[tgj], mj = mol_id[tgj];
-          const D3 d = minimgD(box, posD<R>(xgi) - posD<R>(x4[j]));
-          const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(d.x, d.x), __dmul_rn(d.y, d.y)), __dmul_rn(d.z, d.z));
+          const D3 d = minimgD(box, posD<R>(xgi, box) - posD<R>(x4[j], box));
+          const double d2 = dist2_unfused(d);
           for (int k = 0; k < rs.n; ++k) {
             const ReactionDev& R_ = rs.r[k];
             if (!R_.active) continue;
@@ -2812,6 +2906,7 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
             if (!R_.intraresidual && ri == rj) continue;
             if (!R_.intramolecular && mi == mj) continue;
             if (!(d2 >= R_.mincut2 && d2 < R_.cut2)) continue;
+            if (R_.restricted && !conn_allows(conn, tgi, tgj, k)) continue;
             uint32_t rr[4];
             chem_philox::reaction_draw(rs.seed, rs.step, (uint32_t)tgi, (uint32_t)tgj, (uint32_t)k, rr);
             if (R_.prob < 1.0 && !(chem_philox::u01(rr[0]) < R_.prob)) continue;

@@ -173,6 +173,11 @@ class Engine:
                            0 if new_state is None else int(new_state), 0, float(new_mass), float(new_q))
         self._ck(self.api.reaction_neighbour_change(self.ctx, C.byref(r)))
 
+    def reaction_restrict(self, reaction, id_pairs):
+        """RestrictReaction.define_connection: only these unordered id pairs may react in `reaction` (index from reaction_add)."""
+        p = np.ascontiguousarray(id_pairs, dtype=np.int64).reshape(-1, 2)
+        self._ck(self.api.reaction_restrict(self.ctx, int(reaction), p.shape[0], _ptr(p, C.c_int64)))
+
     def atrp_init(self, interval, num_particles, ratio_activator, ratio_deactivator, delta_catalyst, k_activate, k_deactivate,
                   select_from_all=True, seed=0):
         """integrator.ATRPActivator(system, interval, num_particles, ...) (reaction_post_process.py:380-426)."""

@@ -324,6 +324,29 @@ class _Tabulated(_Pot):
         self.r0, self.dr = float(self.r[0]), float(self.r[1] - self.r[0])
 
 
+class _MixedTabulated(_Pot):
+    """interaction.MixedTabulated(itype, table1, table2, chemical_conversion=None, cutoff=None, mix_value=None)
+    (gromacs_topology.py:756-790, nonbond_params func 10 / 12): U = x * table1 + (1 - x) * table2 with x the value of a
+    ChemicalConversion observable (func 10: followed whenever the observable is computed) or a constant (func 12).
+    Linear interpolation is linear in the rows, so the mixture IS one table: x * rows1 + (1 - x) * rows2 -- re-sent to the
+    engine (chem_nb_table) when x changes; the kernels see an ordinary tabulated pair potential."""
+
+    def __init__(self, itype=1, table1=None, table2=None, chemical_conversion=None, cutoff=None, mix_value=None):
+        if itype != 1:
+            raise NotImplementedError("MixedTabulated itype %r (only linear interpolation, itype=1, is in scope)" % itype)
+        a, b = np.loadtxt(table1), np.loadtxt(table2)
+        if a.shape != b.shape or not np.allclose(a[:, 0], b[:, 0], rtol=0, atol=1e-12):
+            raise ValueError("MixedTabulated: %s and %s are not on the same r grid" % (table1, table2))
+        self.table1, self.table2, self.cutoff = table1, table2, cutoff
+        self.r, self._e, self._f = a[:, 0], (a[:, 1], b[:, 1]), (a[:, 2], b[:, 2])
+        self.r0, self.dr = float(self.r[0]), float(self.r[1] - self.r[0])
+        self.observable = chemical_conversion
+        self.mix_value = 0.0 if mix_value is None else float(mix_value)
+
+    def rows(self, x):
+        return x * self._e[0] + (1.0 - x) * self._e[1], x * self._f[0] + (1.0 - x) * self._f[1]
+
+
 class _TabulatedAngular(_Tabulated):
     """interaction.TabulatedAngular(itype, filename): rows `theta U -dU/dtheta` (radians) of a table_a<N>.pot file."""
 
@@ -448,6 +471,28 @@ class _VerletListTabulated(_VerletListInteraction):
         self.system.engine.nb_table(type1, type2, potential.r0, potential.dr, potential.e, potential.f, potential.cutoff)
 
 
+class _VerletListMixedTabulated(_VerletListInteraction):
+    """interaction.VerletListMixedTabulated(vl).setPotential(type1, type2, MixedTabulated(...)) (gromacs_topology.py:756-790)."""
+    label = "mix_tab"
+
+    def setPotential(self, type1, type2, potential):
+        self._pots[(min(type1, type2), max(type1, type2))] = potential
+
+        def push(x, t1=type1, t2=type2, pot=potential):
+            x = min(max(float(x), 0.0), 1.0)
+            if getattr(pot, "_sent", {}).get((t1, t2)) == x:
+                return
+            e, f = pot.rows(x)
+            self.system.engine.nb_table(t1, t2, pot.r0, pot.dr, e, f, pot.cutoff)
+            pot.__dict__.setdefault("_sent", {})[(t1, t2)] = x
+            pot.mix_value = x
+        if potential.observable is not None:
+            potential.observable.connect(push)
+            push(potential.observable.compute() if self.system.engine.n else 0.0)
+        else:
+            push(potential.mix_value)
+
+
 class _FixedListInteraction(object):
     by_types = False
 
@@ -529,7 +574,7 @@ interaction = _ns(
     FixedTripleListTabulatedAngular=_FixedListInteraction, FixedTripleListTypesTabulatedAngular=_FixedListTypesInteraction,
     FixedPairListLambdaHarmonic=_unsupported("interaction.FixedPairListLambdaHarmonic"),
     VerletListDynamicResolutionLennardJones=_unsupported("interaction.VerletListDynamicResolutionLennardJones"),
-    MixedTabulated=_unsupported("interaction.MixedTabulated"), MultiTabulated=_unsupported("interaction.MultiTabulated"),
+    MixedTabulated=_MixedTabulated, VerletListMixedTabulated=_VerletListMixedTabulated, MultiTabulated=_unsupported("interaction.MultiTabulated"),
 )
 
 
@@ -792,6 +837,21 @@ class _Reaction(object):
             self._system.engine.reaction_set_rate(self._index, v)
 
 
+class _RestrictReaction(_Reaction):
+    """integrator.RestrictReaction(...): a Reaction that only accepts the id pairs given by define_connection(b1, b2)
+    (group option `connectivity_map`, reaction_setup.py:75-78,115-128)."""
+
+    def __init__(self, *a, **kw):
+        _Reaction.__init__(self, *a, **kw)
+        object.__setattr__(self, "_connections", [])
+        object.__setattr__(self, "revert", False)
+
+    def define_connection(self, b1, b2):
+        self._connections.append((int(b1), int(b2)))
+        if self._index is not None:
+            self._system.engine.reaction_restrict(self._index, [(int(b1), int(b2))])
+
+
 class _ChemicalReaction(object):
     """integrator.ChemicalReaction(system, vl, storage, topology_manager, interval): nearest_mode,
     max_per_interval, add_reaction, disconnect (reaction_setup.py:416-427,506)."""
@@ -834,6 +894,10 @@ class _ChemicalReaction(object):
                                       intramolecular=r.intramolecular, intraresidual=r.intraresidual, is_virtual=r.is_virtual,
                                       active=r.active, **kw)
             r._system = self.system
+            if isinstance(r, _RestrictReaction):
+                if r.revert:
+                    raise NotImplementedError("RestrictReaction.revert (dissociation along a connectivity map) is outside the hot-path scope")
+                e.reaction_restrict(r._index, r._connections)
             for pp, which in r._nb_pp:
                 for old_type, prop, nb_level in pp.rules:
                     e.reaction_neighbour_change(r._index, which, old_type, nb_level, int(prop.type), float(prop.mass),
@@ -955,7 +1019,7 @@ integrator = _ns(
     StochasticVelocityRescaling=_StochasticVelocityRescaling,
     BerendsenThermostat=_BerendsenThermostat, BerendsenBarostat=_unsupported("integrator.BerendsenBarostat"),
     Isokinetic=_Isokinetic, LangevinBarostat=_unsupported("integrator.LangevinBarostat"),
-    CapForce=_CapForce, RestrictReaction=_unsupported("integrator.RestrictReaction"),
+    CapForce=_CapForce, RestrictReaction=_RestrictReaction,
     DissociationReaction=_unsupported("integrator.DissociationReaction"), ATRPActivator=_ATRPActivator,
     ReactionCutoffRandom=_unsupported("integrator.ReactionCutoffRandom"), FixDistances=_unsupported("integrator.FixDistances"),
     ChangeInRegion=_unsupported("integrator.ChangeInRegion"), BasicDynamicResolution=_unsupported("integrator.BasicDynamicResolution"),
@@ -997,7 +1061,7 @@ class _PotentialEnergy(_Observable):
         i = self.interaction
         if isinstance(i, _VerletListLennardJones):
             return o["epot_lj"]
-        if isinstance(i, _VerletListTabulated):
+        if isinstance(i, (_VerletListTabulated, _VerletListMixedTabulated)):    # (one tabulated-energy accumulator: plain and mixed tables together)
             return o["epot_tab"]
         h = i.flist.handle
         return o["epot_list"][h] if h is not None else 0.0
@@ -1039,7 +1103,13 @@ class _ChemicalConversion(_Observable):
     def compute(self):
         t = self.system.engine.get_state("TYPE")
         c = float((t == self.type_id).sum())
-        return c / self.total if self.total else c
+        val = c / self.total if self.total else c
+        for fn in getattr(self, "_listeners", ()):       # the reference's onValue signal: MixedTabulated follows the conversion
+            fn(val)
+        return val
+
+    def connect(self, fn):
+        self.__dict__.setdefault("_listeners", []).append(fn)
 
 
 class _ChemicalConversionTypeState(_Observable):

@@ -208,8 +208,9 @@ def main(argv=None, hooks=None, quiet=False):
         cad = cadence(args, cr_interval)
         log("Change integrator step to %d" % cad["integrator_step"])
     table_groups = args.table_groups.split(",") if args.table_groups else []
+    cr_observs = {}                                       # conversion observables of mixed tables (start_simulation.py:298-299)
     gromacs_topology.set_nonbonded_interactions(espressopp, system, gt, verletlist, lj_cutoff, tab_cutoff=cg_cutoff, tables_=table_groups,
-                                                table_dir=os.path.dirname(os.path.abspath(args.top)))
+                                                table_dir=os.path.dirname(os.path.abspath(args.top)), cr_observs=cr_observs)
     bonded = gromacs_topology.set_bonded_interactions(espressopp, system, gt, dynamic_types,
                                                       table_dir=os.path.dirname(os.path.abspath(args.top)))
     angles = gromacs_topology.set_angle_interactions(espressopp, system, gt, dynamic_types,
@@ -268,6 +269,9 @@ def main(argv=None, hooks=None, quiet=False):
         mon.add_observable(system.getNameOfInteraction(k), espressopp.analysis.PotentialEnergy(system, system.getInteraction(k)), False)
     for i, (gname, fpl, _) in enumerate(chem_fpls):
         mon.add_observable("count_%d" % i, espressopp.analysis.NFixedPairListEntries(system, fpl))
+    for (cr_type, cr_total, _), obs in sorted(cr_observs.items(), key=lambda kv: kv[0][:2]):
+        # computed with every energy row: that is also what moves the mixed (func 10) tables along with the conversion
+        mon.add_observable("cr_%s_%s" % (cr_type, cr_total), obs)
     integrator.addExtension(espressopp.integrator.ExtAnalyze(mon, cad["energy_collect"]))
     # trajectory + topology writer (start_simulation.py:571-657): H5MD tree, see espp._DumpH5MD for the on-disk form
     traj_file = espressopp.io.DumpH5MD(

@@ -203,6 +203,21 @@ def trimer_melt(n_mol=200, rho=0.27, rc=2.5, skin=0.4, dt=0.0025, kT=1.0, gamma=
     return spec
 
 
+def snap_to_grid(spec):
+    """Positions exactly representable in BOTH precisions of the engine: the fp32 build stores int32 fixed-point coordinates
+    q = rint((x - L/2) / s), s = L / 2^31 (md_kernels.hpp "position codec") and decodes them as q * s + L/2 in fp64, which
+    is what this returns -- frozen-configuration tests feed the same bits to the oracle and to both builds."""
+    L = np.asarray(spec["box"], dtype=np.float64)
+    s = L / 2147483648.0
+    x = np.asarray(spec["pos"], dtype=np.float64)
+    xf = x - np.floor(x / L) * L
+    q = np.rint((xf - 0.5 * L) / s)
+    q = np.where(q >= 2 ** 30, q - 2 ** 31, q)
+    out = dict(spec)
+    out["pos"] = q * s + 0.5 * L
+    return out
+
+
 def apply(spec, eng, thermostat=True, reactions=True):
     """Issue the set-up calls for `spec` on Engine `eng`; returns dict of list handles."""
     eng.set_box(spec["box"])

@@ -266,6 +266,10 @@ typedef struct chem_nb_change {
   double  new_mass, new_q;
 } chem_nb_change;
 int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* rule);
+/* integrator.RestrictReaction(...).define_connection(b1, b2)  reaction_setup.py:75-78,115-128 (group option
+ * `connectivity_map`: a file of id pairs): reaction `reaction` only accepts candidate pairs whose unordered id pair was
+ * defined; everything else about the reaction is unchanged.  Calls accumulate. */
+int chem_reaction_restrict(chem_ctx* ctx, int reaction, int64_t n, const int64_t* id_pairs);
 /* integrator.ATRPActivator(system, interval, num_particles, ratio_activator, ratio_deactivator, delta_catalyst,
  *     k_activate, k_deactivate) + .select_from_all + add_reactive_center(type_id, state, is_activator, new_property,
  *     delta_state)  -- src/chemlab/reaction_post_process.py:380-426, examples/atrp_lj/atrp.cfg:15-25.  An integrator

@@ -110,6 +110,8 @@ struct Orc {
   int interval = 0, nearest = 1, max_per_interval = 0; uint64_t react_seed = 0;
   std::vector<chem_reaction_desc> reactions;
   std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty
+  std::map<std::pair<int32_t, int32_t>, uint32_t> restrict_map;   // RestrictReaction.define_connection: (tag lo, tag hi) -> reaction bits
+  uint32_t restricted_mask = 0;
   // integrator.ATRPActivator (reaction_post_process.py:380-426)
   struct AtrpCenter { int type, state, is_activator, new_type, delta_state; double new_mass, new_q; };
   bool atrp_on = false; chem_atrp_desc atrp{}; std::vector<AtrpCenter> atrp_centers; std::vector<chem_atrp_stats> atrp_stats;
@@ -620,6 +622,10 @@ static void react(Orc& o) {
       Vec3 d = minimg(o, o.x[a] - o.x[b]);
       double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
       if (!(d2 >= R.min_cutoff * R.min_cutoff && d2 < R.cutoff * R.cutoff)) continue;
+      if ((o.restricted_mask >> ri) & 1u) {   // RestrictReaction: only the connections of the map (reaction_setup.py:115-128)
+        auto it = o.restrict_map.find({lo, hi});
+        if (it == o.restrict_map.end() || !((it->second >> ri) & 1u)) continue;
+      }
       double prob = R.rate * o.dt * (double)o.interval;
       uint32_t rr[4];
       chem_philox::reaction_draw(o.react_seed, (uint64_t)o.step, (uint32_t)lo, (uint32_t)hi, (uint32_t)ri, rr);
@@ -946,6 +952,16 @@ int orc_reaction_neighbour_change(void* c, const chem_nb_change* r) {
   o.nb_rules.push_back(*r); return 0;
 }
 
+int orc_reaction_restrict(void* c, int reaction, int64_t n, const int64_t* p) {
+  Orc& o = O(c);
+  if (reaction < 0 || reaction >= (int)o.reactions.size() || reaction >= 32) FAIL(CHEM_EINVAL, "reaction_restrict: reaction index");
+  for (int64_t k = 0; k < n; ++k) {
+    auto a = o.id2tag.find(p[2 * k]), b = o.id2tag.find(p[2 * k + 1]);
+    if (a == o.id2tag.end() || b == o.id2tag.end()) FAIL(CHEM_EINVAL, "reaction_restrict: unknown id");
+    o.restrict_map[{std::min(a->second, b->second), std::max(a->second, b->second)}] |= 1u << reaction;
+  }
+  o.restricted_mask |= 1u << reaction; return 0;
+}
 int orc_atrp_init(void* c, const chem_atrp_desc* d) {
   Orc& o = O(c);
   if (!d) { o.atrp_on = false; return 0; }

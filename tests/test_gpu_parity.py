@@ -13,12 +13,13 @@ import pytest
 
 from chemlab_amd import workloads as W
 from conftest import rel_err
-from helpers import sorted_events, total_epot
+from helpers import force_error_without_cutoff_flips, sorted_events, total_epot
 
 pytestmark = pytest.mark.gpu
 
 TOL = {64: 1e-10, 32: 5e-5}
 TOL_STIFF32 = 5e-4      # systems with K = 1.6e5 harmonic bonds (mf/espp_cg_1 force field), fp32 coordinates
+TOL_MELT32 = 2e-5       # fp32 pair forces of a melt, cutoff-boundary decisions set apart (helpers.force_error_without_cutoff_flips)
 
 
 def both(make_gpu, make_oracle, spec, prec, **kw):
@@ -208,8 +209,8 @@ def test_reaction_scan_frozen_positions_bit_identical(make_gpu, make_oracle, pre
     """One React() on frozen, fp32-representable positions: candidate resolve, new bonds,
     state and type vectors must be bit-identical; r^2 is evaluated in fp64 on both sides."""
     spec = W.reactive_melt(n=8788, seed=11, interval=1, rho=0.8442)   # 13^3*4
-    spec["pos"] = spec["pos"].astype(np.float32).astype(np.float64)
     spec["box"] = [float(np.float32(spec["box"][0]))] * 3
+    spec = W.snap_to_grid(spec)        # positions both builds represent exactly (fp32 build: int32 fixed point)
     spec["dt"] = 1e-9
     spec["vel"] = np.zeros_like(spec["vel"])
     for r in spec["reaction"]["reactions"]:
@@ -718,7 +719,9 @@ def test_baseline_c2_32k_lj_melt(make_gpu, make_oracle):
     spec = dict(spec, pos=m.get_state("POS"), vel=m.get_state("VEL"))
     g, o, _ = both(make_gpu, make_oracle, spec, 32, thermostat=False)
     g.run(0); o.run(0)
-    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[32]
+    # a melt has pairs within rounding of rc, where the truncated LJ force jumps by 0.039: those decisions are set apart
+    err, flips = force_error_without_cutoff_flips(spec, g.get_state("FORCE"), o.get_state("FORCE"), TOL_MELT32, max_flips=8)
+    assert err < TOL_MELT32 and 0 <= flips <= 8, (err, flips)
     og, oo = g.observe(), o.observe()
     assert og["epot_lj"] == pytest.approx(oo["epot_lj"], rel=2e-6)
     assert og["virial_nb"] == pytest.approx(oo["virial_nb"], rel=1e-5)
@@ -751,8 +754,8 @@ def test_baseline_c4_256k_reactive_one_reaction_step(make_gpu, make_oracle):
     """256k monomers, one reaction step on frozen fp32-representable positions: the candidate scan over the
     staged tiles, the resolve and the topology update must give the oracle's events, bonds, states and types."""
     spec = W.reactive_melt(n=256000, rho=0.8, seed=5, interval=1)
-    spec["pos"] = spec["pos"].astype(np.float32).astype(np.float64)
     spec["box"] = [float(np.float32(spec["box"][0]))] * 3
+    spec = W.snap_to_grid(spec)        # positions both builds represent exactly (fp32 build: int32 fixed point)
     spec["dt"] = 1e-9
     spec["vel"] = np.zeros_like(spec["vel"])
     for r in spec["reaction"]["reactions"]:
@@ -777,7 +780,8 @@ def test_baseline_c4_256k_forces_energy_and_reactive_trajectory(make_gpu, make_o
     g.run(0); o.run(0)
     gf, of = g.get_state("FORCE"), o.get_state("FORCE")
     # the thermostat adds the same keyed noise on both sides (evaluation phase 0); pair part from the lists
-    assert rel_err(gf, of) < TOL[32]
+    err, flips = force_error_without_cutoff_flips(spec, gf, of, TOL_MELT32, max_flips=40)
+    assert err < TOL[32] and 0 <= flips <= 40, (err, flips)
     og, oo = g.observe(), o.observe()
     assert og["epot_lj"] == pytest.approx(oo["epot_lj"], rel=2e-6)
     assert og["virial_nb"] == pytest.approx(oo["virial_nb"], rel=1e-5)

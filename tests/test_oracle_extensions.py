@@ -94,3 +94,81 @@ def test_atrp_cfg_of_the_shipped_example_parses():
     ext = cfg["extensions"]["atrp"]
     assert ext["ext_type"] == "ATRPActivator" and ext["options"].count("->") == 4
     assert cfg["reactions"]["reaction_1"]["extensions"] == ["atrp", "change_neighbour_type"]
+
+
+def test_mixed_tabulated_follows_the_conversion(tmp_path, oracle_mod):
+    """nonbond_params func 10 (gromacs_topology.py:574-583,756-790): U = x * table1 + (1 - x) * table2 with x the chemical
+    conversion (particles of a type / total).  Known answer through the shim on the oracle: pair energy and force of two
+    particles at a distance between grid points, before and after the conversion observable moves."""
+    from chemlab_amd import espp
+    r = 0.002 * np.arange(1, 1001)
+    t1 = np.stack([r, 3.0 * (1.0 - r / 2.0) ** 2, 3.0 * (1.0 - r / 2.0)], 1)          # U = 3 (1 - r/2)^2, f = -dU/dr
+    t2 = np.stack([r, 1.0 * np.exp(-r), 1.0 * np.exp(-r)], 1)
+    np.savetxt(tmp_path / "t1.pot", t1, fmt="%15.8g"); np.savetxt(tmp_path / "t2.pot", t2, fmt="%15.8g")
+    t1, t2 = np.loadtxt(tmp_path / "t1.pot"), np.loadtxt(tmp_path / "t2.pot")              # (the 8 significant digits of the file format)
+    r = t1[:, 0]
+    espp.set_engine_factory(lambda: oracle_mod.OracleEngine())
+    try:
+        system = espp.System()
+        system.rng = espp.esutil.RNG(3)
+        system.skin = 0.2
+        box = (12.0, 12.0, 12.0)
+        system.bc = espp.bc.OrthorhombicBC(system.rng, box)
+        system.storage = espp.storage.DomainDecomposition(system, espp.tools.decomp.nodeGrid(1), espp.tools.decomp.cellGrid(box, (1, 1, 1), 1.5, 0.2))
+        integrator = espp.integrator.VelocityVerlet(system)
+        integrator.dt = 1e-5
+        d = 0.7313
+        plist = [[1, 0, espp.Real3D(3.0, 3.0, 3.0), 1.0], [2, 0, espp.Real3D(3.0 + d, 3.0, 3.0), 1.0]] + \
+                [[3 + k, 1, espp.Real3D(8.0, 2.0 + 2.0 * k, 8.0), 1.0] for k in range(4)]          # four far-away particles of type 1
+        system.storage.addParticles(plist, "id", "type", "pos", "mass")
+        system.storage.decompose()
+        vl = espp.VerletList(system, cutoff=1.5, exclusionlist=espp.DynamicExcludeList(integrator, []))
+        obs = espp.analysis.ChemicalConversion(system, 2, 4)                                      # fraction of the 4 that became type 2
+        mix = espp.interaction.VerletListMixedTabulated(vl)
+        mix.setPotential(type1=0, type2=0, potential=espp.interaction.MixedTabulated(1, str(tmp_path / "t1.pot"), str(tmp_path / "t2.pot"), obs, cutoff=1.5))
+        system.addInteraction(mix, "lj-mix_tab")
+        pe = espp.analysis.PotentialEnergy(system, mix)
+
+        def want(x):
+            e = x * np.interp(d, r, t1[:, 1]) + (1 - x) * np.interp(d, r, t2[:, 1])
+            f = x * np.interp(d, r, t1[:, 2]) + (1 - x) * np.interp(d, r, t2[:, 2])
+            return e, f
+        e0, f0 = want(0.0)
+        assert abs(pe.compute() - e0) < 1e-9 * abs(e0)
+        integrator.run(0)
+        assert abs(system.engine.get_state("FORCE")[1, 0] - f0) < 1e-9 * abs(f0)
+        system.storage.modifyParticle(4, "type", 2)                                               # conversion 1/4 ...
+        system.storage.modifyParticle(5, "type", 2)                                               # ... 2/4
+        assert obs.compute() == 0.5                                                               # computing the observable moves the table
+        e1, f1 = want(0.5)
+        assert abs(pe.compute() - e1) < 1e-9 * abs(e1)
+        integrator.run(0)
+        assert abs(system.engine.get_state("FORCE")[1, 0] - f1) < 1e-9 * abs(f1)
+        # func 12: a constant mixture
+        mix.setPotential(type1=0, type2=0, potential=espp.interaction.MixedTabulated(1, table1=str(tmp_path / "t1.pot"), table2=str(tmp_path / "t2.pot"), mix_value=0.8, cutoff=1.5))
+        e2, _ = want(0.8)
+        assert abs(pe.compute() - e2) < 1e-9 * abs(e2)
+    finally:
+        from chemlab_amd.engine import Engine
+        espp.set_engine_factory(lambda: Engine(device=0, precision=32))
+
+
+def test_restrict_reaction_only_mapped_pairs_react(make_oracle):
+    """RestrictReaction.define_connection (reaction_setup.py:75-78,115-128): with a connectivity map only the listed id
+    pairs may react; every event of the restricted reaction is a mapped pair, the other reactions are untouched."""
+    spec = W.reactive_melt(n=4000, seed=23, interval=5)
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e9
+    free, res = make_oracle(), make_oracle()
+    W.apply(spec, free); W.apply(spec, res)
+    free.run(20)
+    ev = free.get_events()
+    bonding = ev[ev["reaction"] == 1]
+    assert len(bonding) > 20
+    allowed = np.stack([bonding["id_a"], bonding["id_b"]], 1)[::2]           # every second bond-forming pair of the free run
+    res.reaction_restrict(1, allowed)
+    res.run(20)
+    ev2 = res.get_events()
+    got = {tuple(sorted(p)) for p in np.stack([ev2["id_a"], ev2["id_b"]], 1)[ev2["reaction"] == 1].tolist()}
+    assert got and got <= {tuple(sorted(p)) for p in allowed.tolist()}
+    assert (ev2["reaction"] == 0).sum() > 0                                  # unrestricted reactions still fire
