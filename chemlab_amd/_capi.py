@@ -51,7 +51,7 @@ class ReactionDesc(C.Structure):
 class NbChange(C.Structure):
     _fields_ = [("reaction", C.c_int32), ("invoke_on", C.c_int32), ("old_type", C.c_int32), ("nb_level", C.c_int32),
                 ("new_type", C.c_int32), ("set_state", C.c_int32), ("new_state", C.c_int32), ("pad", C.c_int32),
-                ("new_mass", C.c_double), ("new_q", C.c_double)]
+                ("new_mass", C.c_double), ("new_q", C.c_double), ("min_state", C.c_int32), ("max_state", C.c_int32)]
 
 
 class AtrpDesc(C.Structure):
@@ -120,6 +120,7 @@ SIGNATURES = {
     "reaction_add": (_i, [_P, C.POINTER(ReactionDesc)]),
     "reaction_neighbour_change": (_i, [_P, C.POINTER(NbChange)]),
     "reaction_restrict": (_i, [_P, _i, _i64, _pi64]),
+    "reaction_constraint": (_i, [_P, _i, _i, _i, _i, _i]),
     "atrp_init": (_i, [_P, C.POINTER(AtrpDesc)]),
     "atrp_add_center": (_i, [_P, _i, _i, _i, _i, _d, _d, _i]),
     "atrp_get_stats": (_i64, [_P, C.POINTER(AtrpStats), _i64]),

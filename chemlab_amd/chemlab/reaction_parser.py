@@ -8,6 +8,7 @@ import configparser
 import re
 
 REACTION_NORMAL = "normal"
+REACTION_EXCHANGE = "exchange"
 
 _RE_REACTANT = re.compile(r"(?P<name>\w+)\((?P<min>\d+),\s*(?P<max>\d+)\)")
 _RE_PRODUCT = re.compile(r"(?P<name>\w+)\((?P<delta>[0-9-]+)\)")
@@ -33,6 +34,21 @@ def parse_equation(text):
     return rl, REACTION_NORMAL
 
 
+def parse_exchange_equation(text):
+    """`A(a,b):B(c,d) + C(e,f) -> A'(dA):C'(dC) + B'(dB)` (reaction_parser.py:98-127): type_1 = A, type_2 = B (the leaving
+    group, takes the product behind the `+`), type_3 = C (takes the second product of the `:` pair)."""
+    re_prod = re.compile(r"(?P<new_type>\w+)\((?P<delta>[0-9-]+)\)")
+    reactants, products = (t.strip() for t in text.split("->"))
+    part_a, part_b = [[p.strip() for p in x.split(":")] for x in reactants.split("+")]
+    mol_a, mol_b = (_RE_REACTANT.match(p).groupdict() for p in part_a)
+    mol_c = _RE_REACTANT.match(part_b[0]).groupdict()
+    prod_a, prod_b = [[p.strip() for p in x.split(":")] for x in products.split("+")]
+    pa, pb = (re_prod.match(p).groupdict() for p in prod_a)
+    pc = re_prod.match(prod_b[0]).groupdict()
+    mol_a.update(pa); mol_b.update(pc); mol_c.update(pb)
+    return {"type_1": mol_a, "type_2": mol_b, "type_3": mol_c}, REACTION_EXCHANGE
+
+
 def _literal(v, default=False):
     if v is None:
         return default
@@ -49,10 +65,17 @@ def process_reaction(sec):
             "exclude_extensions": set(), "equation": sec["reaction"], "active": _literal(sec.get("active"), True)}
     if "exclude_extensions" in sec:
         data["exclude_extensions"] = {s.strip() for s in sec["exclude_extensions"].split(",")}
-    try:
-        data["reactant_list"], data["reaction_type"] = parse_equation(sec["reaction"])
-    except ValueError as e:
-        raise NotImplementedError("only normal reactions A(a,b) + B(c,d) -> A'(x):B'(y) are in scope: %s" % e)
+    eq = sec["reaction"]
+    left = eq.split("->")[0]
+    if ":" in left and "+" in left:             # A:B + C -> A:C + B  (reaction_parser.py:98-127)
+        data["reactant_list"], data["reaction_type"] = parse_exchange_equation(eq)
+    elif ":" in left:                           # A:B -> A + B: dissociation needs BasicDynamicResolution (AdResS), out of scope
+        raise NotImplementedError("dissociation reactions A(a,b):B(c,d) -> A'(x) + B'(y) need the dynamic-resolution machinery (reaction_setup.py:253-356), out of scope")
+    else:
+        try:
+            data["reactant_list"], data["reaction_type"] = parse_equation(eq)
+        except ValueError as e:
+            raise NotImplementedError("cannot parse reaction %r: %s" % (eq, e))
     if "min_cutoff" in sec:
         data["min_cutoff"] = float(sec["min_cutoff"])
     if "sigma" in sec and "eq_distance" in sec:

@@ -47,6 +47,41 @@ class SetupReactions(object):
                 self.dynamic_types.update((n2t[old], n2t[new]))
         return r
 
+    def _setup_reaction_exchange(self, cr, fpl):
+        """`A:B + C -> A:C + B` (reaction_setup.py:167-251): a VIRTUAL A + C reaction -- no bond is made or removed, the event
+        only changes properties -- that requires A to carry a bonded B in B's state window; A changes type like a normal
+        reactant, the B neighbours of A in the window take B's new type and have their state incremented."""
+        e, rl, n2t = self.espp, cr["reactant_list"], self.name2type
+        if cr.get("connectivity_map"):
+            raise RuntimeError("connectivity_map not supported by exchange reaction")
+        rt1, rt2, rt3 = rl["type_1"], rl["type_2"], rl["type_3"]
+        r = e.integrator.Reaction(
+            type_1=n2t[rt1["name"]], type_2=n2t[rt3["name"]], delta_1=int(rt1["delta"]), delta_2=int(rt3["delta"]),
+            min_state_1=int(rt1["min"]), max_state_1=int(rt1["max"]), min_state_2=int(rt3["min"]), max_state_2=int(rt3["max"]),
+            rate=float(cr["rate"]), fpl=fpl, cutoff=float(cr["cutoff"]))
+        r.is_virtual = True
+        r.add_constraint(e.integrator.ReactionConstraintNeighbourState(n2t[rt2["name"]], int(rt2["min"]), int(rt2["max"])), "type_1")
+        r.intraresidual = bool(cr["intraresidual"])
+        r.intramolecular = bool(cr["intramolecular"])
+        if "min_cutoff" in cr:
+            r.get_reaction_cutoff().min_cutoff = float(cr["min_cutoff"])
+        r.active = cr.get("active", True)
+        t1_old, t1_new = n2t[rt1["name"]], n2t[rt1["new_type"]]
+        t2_old, t2_new = n2t[rt2["name"]], n2t[rt2["new_type"]]
+        self.dynamic_types.update((t1_old, t1_new, t2_old, t2_new, n2t[rt3["name"]]))
+        if t1_old != t1_new:
+            pp = e.integrator.PostProcessChangePropertyByTopologyManager(self.tm)
+            prop = self.topol.gt.atomtypes[rt1["new_type"]]
+            pp.add_change_property(t1_old, e.integrator.TopologyParticleProperties(type=t1_new, mass=prop["mass"], q=prop["charge"]))
+            r.add_postprocess(pp, "type_1")
+        prop = self.topol.gt.atomtypes[rt2["new_type"]]
+        tpp = e.integrator.TopologyParticleProperties(type=t2_new, mass=prop["mass"], q=prop["charge"], incr_state=int(rt2["delta"]))
+        tpp.set_min_max_state(int(rt2["min"]), int(rt2["max"]))
+        nb = e.integrator.PostProcessChangeNeighboursProperty(self.tm)
+        nb.add_change_property(t2_old, tpp, 1)
+        r.add_postprocess(nb, "type_1")
+        return r
+
     def _setup_extension(self, name):
         """[ext_<name>] -> (post-process object, invoke_on).  In scope: ChangeNeighboursProperty
         (reaction_post_process.py:76-115: `type_transfers=OLD:level->NEW[(state=1,...)],...`)."""
@@ -123,7 +158,7 @@ class SetupReactions(object):
             self.fpls.append((gname, fpl, inter))
             for cr in group["reaction_list"]:
                 cr["connectivity_map"] = group.get("connectivity_map")      # group level -> reaction level (reaction_setup.py:488)
-                r = self._setup_reaction_normal(cr, fpl)
+                r = self._setup_reaction_exchange(cr, fpl) if cr.get("reaction_type") == "exchange" else self._setup_reaction_normal(cr, fpl)
                 for name, (pp, invoke_on) in group_pp:        # reaction_setup.py:495-505
                     if name not in cr.get("exclude_extensions", []):
                         r.add_postprocess(pp, invoke_on)

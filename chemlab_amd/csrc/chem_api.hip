@@ -96,6 +96,8 @@ struct Ctx {
   std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty (chem_reaction_neighbour_change)
   // RestrictReaction.define_connection (chem_reaction_restrict): (tag lo, tag hi) -> reaction bits; CSR rebuilt when it changed
   std::map<std::pair<int32_t, int32_t>, uint32_t> restrict_map; uint32_t restricted_mask = 0; bool restrict_dirty = false;
+  struct NbCons { int role = 0, nb_type = 0, min_state = 0, max_state = 0; };   // ReactionConstraintNeighbourState (chem_reaction_constraint)
+  std::vector<NbCons> constraints;
   // integrator.ATRPActivator (chem_atrp_init; reaction_post_process.py:380-426)
   struct AtrpCenter { int type, state, is_activator, new_type, delta_state; double new_mass, new_q; };
   bool atrp_on = false; chem_atrp_desc atrp{}; std::vector<AtrpCenter> atrp_centers; std::vector<chem_atrp_stats> atrp_stats;
@@ -279,7 +281,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> st0, st1, asA, asB, evcount;
   DBuf<unsigned long long> best1, best2;
   DBuf<ReactSet> rs_dev;
-  DBuf<int> conn_start, conn_partner; DBuf<unsigned int> conn_mask;
+  DBuf<int> conn_start, conn_partner; DBuf<unsigned int> conn_mask, cons_ok;
   Box<R> box{}; BoxD boxd{};
   bool device_ready = false;
   // per-kernel HIP-event samples of the timed region (option time_pair_kernel = N: every N-th step)
@@ -1356,6 +1358,7 @@ template <typename R> struct CtxT : Ctx {
       r.min1 = d.min_state_1; r.max1 = d.max_state_1; r.min2 = d.min_state_2; r.max2 = d.max_state_2;
       r.intramolecular = d.intramolecular; r.intraresidual = d.intraresidual; r.active = d.active;
       r.restricted = (restricted_mask >> q) & 1u;
+      r.cons_role = q < (int)constraints.size() ? constraints[q].role : 0; r.pad_ = 0;
       r.cut2 = d.cutoff * d.cutoff; r.mincut2 = d.min_cutoff * d.min_cutoff; r.prob = d.rate * dt * (double)interval;
       ras.r[q] = ReactApply{d.delta_1, d.delta_2, d.new_type_1, d.new_type_2, d.new_mass_1, d.new_mass_2};
     }
@@ -1380,7 +1383,26 @@ template <typename R> struct CtxT : Ctx {
       conn_start.upload(hs, stream); conn_partner.upload(hp, stream); conn_mask.upload(hm, stream);
       restrict_dirty = false;
     }
-    const ConnTable conn{restricted_mask ? conn_start.p : nullptr, conn_partner.p, conn_mask.p};
+    bool any_cons = false;
+    for (auto& cs : constraints) any_cons |= cs.role != 0;
+    if (any_cons) {
+      // neighbour-state constraints: evaluated on the host per particle from the bond graph and the current states and
+      // types (the graph lives here; candidates carrying a constraint are rare), one bit per reaction
+      if (state_mirror_stale) { std::vector<int> hs; state.download(hs, nglob, stream); top.state.assign(hs.begin(), hs.end()); state_mirror_stale = false; }
+      sync_type_mirrors();
+      std::vector<unsigned int> ok((size_t)nglob, 0u);
+      for (size_t q = 0; q < constraints.size(); ++q) {
+        const NbCons& cs = constraints[q];
+        if (!cs.role) continue;
+        const int own_type = cs.role == 1 ? reactions[q].type_1 : reactions[q].type_2;
+        for (int32_t t = 0; t < (int32_t)nglob; ++t) {
+          if (top.type[t] != own_type) continue;
+          for (int32_t nb : top.graph[t]) if (top.type[nb] == cs.nb_type && top.state[nb] >= cs.min_state && top.state[nb] < cs.max_state) { ok[t] |= 1u << q; break; }
+        }
+      }
+      cons_ok.upload(ok, stream);
+    }
+    const ConnTable conn{restricted_mask ? conn_start.p : nullptr, conn_partner.p, conn_mask.p, any_cons ? cons_ok.p : nullptr};
     if (use_tiles) {
       const int region_cap = std::max(1, cand_cap / std::max(ntiles, 1));
       tile_cnt.alloc(ntiles + 1); tile_off.alloc(ntiles + 1);
@@ -1556,6 +1578,11 @@ template <typename R> struct CtxT : Ctx {
       std::vector<Candidate> ord;
       for (auto& e : hev) for (auto& rl : nb_rules) if (rl.reaction == e.r) { ord.push_back(e); break; }
       std::sort(ord.begin(), ord.end(), [&](const Candidate& p, const Candidate& q) { return ekey(p) < ekey(q); });
+      bool reads_state = false;
+      for (auto& rl : nb_rules) reads_state |= rl.set_state == 2 || rl.min_state < rl.max_state;
+      if (reads_state) {      // states as the events of this step left them (k_react_apply ran on the device)
+        std::vector<int> hs; state.download(hs, nglob, stream); top.state.assign(hs.begin(), hs.end()); state_mirror_stale = false;
+      }
       std::vector<HostTopology::PropChange> chg;
       for (auto& e : ord)
         for (int role = 1; role <= 2; ++role)
@@ -1567,6 +1594,7 @@ template <typename R> struct CtxT : Ctx {
       hipLaunchKernelGGL((k_apply_props<R>), dim3(cdiv((long long)chg.size(), 256)), dim3(256), 0, stream, (int)chg.size(), dchg.p, state.p, rtag.p, x4.p, v4.p);
       HIPCHK(hipStreamSynchronize(stream));
       types_changed = true;
+      if (!reads_state) state_mirror_stale = true;      // (rules that set a state moved the device copy, not a refreshed mirror)
     };
     if (!newbonds.empty() && !nb_rules.empty()) {
       // same dependency order as below, fully synchronous: graph -> (labels on the thread) -> spawned tuples (types as
@@ -2212,6 +2240,18 @@ int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* r) {
   REQUIRE(r->new_mass > 0, CHEM_EINVAL, "neighbour_change: new_mass");
   REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "neighbour property changes on the decomposed path");
   c.nb_rules.push_back(*r); c.pair_dirty = true;
+  return 0;
+  API_END(ctx)
+}
+
+int chem_reaction_constraint(chem_ctx* ctx, int reaction, int role, int nb_type, int min_state, int max_state) {
+  API_BEGIN
+  Ctx& c = CTX;
+  REQUIRE(reaction >= 0 && reaction < (int)c.reactions.size() && reaction < 32, CHEM_EINVAL, "reaction_constraint: reaction index");
+  REQUIRE((role == 1 || role == 2) && nb_type >= 0 && nb_type < CHEM_MAX_TYPES, CHEM_EINVAL, "reaction_constraint: role must be 1 or 2, nb_type a type id");
+  REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "reaction constraints on the decomposed path");
+  if (c.constraints.size() < c.reactions.size()) c.constraints.resize(c.reactions.size());
+  c.constraints[reaction] = Ctx::NbCons{role, nb_type, min_state, max_state};
   return 0;
   API_END(ctx)
 }

@@ -268,8 +268,13 @@ struct HostTopology {
     std::sort(nb_frontier.begin(), nb_frontier.end());
     for (int32_t p : nb_frontier) {
       if (type[p] != rl.old_type) continue;
+      // (rules with a state window or an increment read the state mirror: the caller refreshes it from the device first)
+      if (rl.min_state < rl.max_state && !(state[p] >= rl.min_state && state[p] < rl.max_state)) continue;
       type[p] = rl.new_type; mass[p] = rl.new_mass; q[p] = rl.new_q;
-      out.push_back(PropChange{p, rl.new_type, rl.set_state, rl.new_state, rl.new_mass, rl.new_q});
+      int32_t st_abs = rl.new_state;
+      if (rl.set_state == 2) st_abs = state[p] + rl.new_state;
+      if (rl.set_state) state[p] = st_abs;
+      out.push_back(PropChange{p, rl.new_type, rl.set_state ? 1 : 0, st_abs, rl.new_mass, rl.new_q});
     }
   }
 

@@ -2650,11 +2650,12 @@ struct ReactionDev {
   int type_1, type_2, delta_1, delta_2;
   int min1, max1, min2, max2;
   int intramolecular, intraresidual, active, restricted;   // restricted: RestrictReaction -- only pairs of the connection table react
+  int cons_role, pad_;   // ReactionConstraintNeighbourState on role 1 | 2: the host evaluates it per particle into a bit table (ConnTable::cons_ok)
   double cut2, mincut2, prob;
 };
 struct ReactSet { int n; uint64_t seed; uint64_t step; int nearest; ReactionDev r[CHEM_MAX_REACTIONS]; };
 // RestrictReaction.define_connection (reaction_setup.py:115-128): per-tag CSR of the allowed partners, one bit per reaction
-struct ConnTable { const int* start; const int* partner; const unsigned int* mask; };
+struct ConnTable { const int* start; const int* partner; const unsigned int* mask; const unsigned int* cons_ok; };   // cons_ok[tag]: bit q = constraint of reaction q holds
 __device__ __forceinline__ bool conn_allows(const ConnTable& ct, int ta, int tb, int q) {
   if (!ct.start) return false;
   for (int e = ct.start[ta]; e < ct.start[ta + 1]; ++e) if (ct.partner[e] == tb) return (ct.mask[e] >> q) & 1u;
@@ -2748,6 +2749,7 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
             if (!R_.intramolecular && mi == mj) hit = false;
             if (!(d2 >= R_.mincut2 && d2 < R_.cut2)) hit = false;
             if (hit && R_.restricted && !conn_allows(conn, tgi, tgj, q)) hit = false;
+            if (hit && R_.cons_role && !((conn.cons_ok[R_.cons_role == 1 ? a : b] >> q) & 1u)) hit = false;
             if (hit) {
               uint32_t rr[4];
               chem_philox::reaction_draw(rs.seed, rs.step, (uint32_t)tgi, (uint32_t)tgj, (uint32_t)q, rr);
@@ -2907,6 +2909,7 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
             if (!R_.intramolecular && mi == mj) continue;
             if (!(d2 >= R_.mincut2 && d2 < R_.cut2)) continue;
             if (R_.restricted && !conn_allows(conn, tgi, tgj, k)) continue;
+            if (R_.cons_role && !((conn.cons_ok[(R_.cons_role == 1) == fwd ? tgi : tgj] >> k) & 1u)) continue;   // (role 1 is tgi on a forward match)
             uint32_t rr[4];
             chem_philox::reaction_draw(rs.seed, rs.step, (uint32_t)tgi, (uint32_t)tgj, (uint32_t)k, rr);
             if (R_.prob < 1.0 && !(chem_philox::u01(rr[0]) < R_.prob)) continue;

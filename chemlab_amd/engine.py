@@ -165,13 +165,21 @@ class Engine:
                                bond_list, new_type_1, new_type_2, new_mass_1, new_mass_2, new_q_1, new_q_2)
         return self._ck(self.api.reaction_add(self.ctx, C.byref(d)))
 
-    def reaction_neighbour_change(self, reaction, invoke_on, old_type, nb_level, new_type, new_mass, new_q=0.0, new_state=None):
+    def reaction_neighbour_change(self, reaction, invoke_on, old_type, nb_level, new_type, new_mass, new_q=0.0, new_state=None,
+                                  incr_state=None, state_window=None):
         """PostProcessChangeNeighboursProperty rule for the events of `reaction` (index from reaction_add):
-        invoke_on 'type_1' | 'type_2' | 'both'; new_state None keeps the chemical state."""
+        invoke_on 'type_1' | 'type_2' | 'both'; new_state None keeps the chemical state, incr_state adds to it;
+        state_window (min, max): only neighbours whose state is in [min, max)."""
         io = {"type_1": 1, "type_2": 2, "both": 3, 1: 1, 2: 2, 3: 3}[invoke_on]
-        r = _capi.NbChange(int(reaction), io, int(old_type), int(nb_level), int(new_type), 0 if new_state is None else 1,
-                           0 if new_state is None else int(new_state), 0, float(new_mass), float(new_q))
+        mode, val = (2, int(incr_state)) if incr_state is not None else ((1, int(new_state)) if new_state is not None else (0, 0))
+        lo, hi = (0, 0) if state_window is None else (int(state_window[0]), int(state_window[1]))
+        r = _capi.NbChange(int(reaction), io, int(old_type), int(nb_level), int(new_type), mode, val, 0, float(new_mass), float(new_q), lo, hi)
         self._ck(self.api.reaction_neighbour_change(self.ctx, C.byref(r)))
+
+    def reaction_constraint(self, reaction, role, nb_type, min_state, max_state):
+        """ReactionConstraintNeighbourState on role 'type_1' | 'type_2' of `reaction` (reaction_setup.py:203-204)."""
+        ro = {"type_1": 1, "type_2": 2, 1: 1, 2: 2}[role]
+        self._ck(self.api.reaction_constraint(self.ctx, int(reaction), ro, int(nb_type), int(min_state), int(max_state)))
 
     def reaction_restrict(self, reaction, id_pairs):
         """RestrictReaction.define_connection: only these unordered id pairs may react in `reaction` (index from reaction_add)."""

@@ -720,8 +720,23 @@ class _CapForce(object):
 
 
 class _TopologyParticleProperties(object):
-    def __init__(self, type=None, mass=None, q=None, state=None, **kw):
-        self.type, self.mass, self.q, self.state = type, mass, q, state
+    """integrator.TopologyParticleProperties(type=, mass=, q=, state=, incr_state=) + set_min_max_state(min, max)
+    (reaction_setup.py:245-249: the neighbour changes only while its state is in [min, max), and its state is incremented)."""
+
+    def __init__(self, type=None, mass=None, q=None, state=None, incr_state=None, **kw):
+        self.type, self.mass, self.q, self.state, self.incr_state = type, mass, q, state, incr_state
+        self.min_state = self.max_state = None
+
+    def set_min_max_state(self, min_state, max_state):
+        self.min_state, self.max_state = int(min_state), int(max_state)
+
+
+class _ReactionConstraintNeighbourState(object):
+    """integrator.ReactionConstraintNeighbourState(type_id, min_state, max_state): the constrained reactant must have a
+    bonded neighbour of that type in that state window (reaction_setup.py:203-204)."""
+
+    def __init__(self, type_id, min_state, max_state):
+        self.type_id, self.min_state, self.max_state = int(type_id), int(min_state), int(max_state)
 
 
 class _ATRPActivator(object):
@@ -783,7 +798,10 @@ class _PostProcessChangeNeighboursProperty(object):
 
 
 class _PostProcessChangeProperty(object):
-    def __init__(self):
+    """integrator.PostProcessChangeProperty() and PostProcessChangePropertyByTopologyManager(tm) (reaction_setup.py:225-236):
+    both change type / mass / charge of the reactant itself; here they are the same thing (new_type_* of chem_reaction_desc)."""
+
+    def __init__(self, topology_manager=None):
         self.changes = {}
 
     def add_change_property(self, type_id, prop):
@@ -810,8 +828,14 @@ class _Reaction(object):
         self.active = True
         self._pp = {}
         self._nb_pp = []
+        self._constraints = []
         self._index = None
         self._system = None
+
+    def add_constraint(self, constraint, which="type_1"):
+        if not isinstance(constraint, _ReactionConstraintNeighbourState):
+            raise NotImplementedError("reaction constraint %s is outside the hot-path scope" % type(constraint).__name__)
+        self._constraints.append((constraint, which))
 
     @property
     def cutoff(self):
@@ -898,10 +922,14 @@ class _ChemicalReaction(object):
                 if r.revert:
                     raise NotImplementedError("RestrictReaction.revert (dissociation along a connectivity map) is outside the hot-path scope")
                 e.reaction_restrict(r._index, r._connections)
+            for cons, which in r._constraints:
+                e.reaction_constraint(r._index, which, cons.type_id, cons.min_state, cons.max_state)
             for pp, which in r._nb_pp:
                 for old_type, prop, nb_level in pp.rules:
+                    window = None if getattr(prop, "min_state", None) is None else (prop.min_state, prop.max_state)
                     e.reaction_neighbour_change(r._index, which, old_type, nb_level, int(prop.type), float(prop.mass),
-                                                float(prop.q or 0.0), None if prop.state is None else int(prop.state))
+                                                float(prop.q or 0.0), None if prop.state is None else int(prop.state),
+                                                incr_state=getattr(prop, "incr_state", None), state_window=window)
 
     def _connect(self, integrator):
         self._flush()
@@ -1015,6 +1043,7 @@ class _ExtAnalyze(object):
 integrator = _ns(
     VelocityVerlet=_VelocityVerlet, LangevinThermostat=_LangevinThermostat, ChemicalReaction=_ChemicalReaction,
     Reaction=_Reaction, PostProcessChangeProperty=_PostProcessChangeProperty,
+    PostProcessChangePropertyByTopologyManager=_PostProcessChangeProperty, ReactionConstraintNeighbourState=_ReactionConstraintNeighbourState,
     TopologyParticleProperties=_TopologyParticleProperties, TopologyManager=_TopologyManager, ExtAnalyze=_ExtAnalyze,
     StochasticVelocityRescaling=_StochasticVelocityRescaling,
     BerendsenThermostat=_BerendsenThermostat, BerendsenBarostat=_unsupported("integrator.BerendsenBarostat"),

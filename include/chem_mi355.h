@@ -262,10 +262,16 @@ int chem_topology_register(chem_ctx* ctx, int arity, int list, const int32_t* ty
  * (min id, max id), role 1 before role 2, rules in the order they were added. */
 typedef struct chem_nb_change {
   int32_t reaction, invoke_on, old_type, nb_level;
-  int32_t new_type, set_state, new_state, pad;
+  int32_t new_type, set_state, new_state, pad;   /* set_state 0: keep the state, 1: state = new_state, 2: state += new_state (incr_state) */
   double  new_mass, new_q;
+  int32_t min_state, max_state;                  /* only neighbours whose state is in [min, max) change (set_min_max_state); min >= max: no window */
 } chem_nb_change;
 int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* rule);
+/* reaction.add_constraint(ReactionConstraintNeighbourState(type, min_state, max_state), 'type_1' | 'type_2')
+ * reaction_setup.py:203-204 (exchange reactions `A:B + C -> A:C + B`, which the reference sets up as a virtual A + C reaction
+ * that requires A to carry a B): a candidate pair is accepted only if the particle in role `role` (1 | 2) has a bonded
+ * neighbour of type nb_type whose chemical state is in [min_state, max_state).  One constraint per reaction and role. */
+int chem_reaction_constraint(chem_ctx* ctx, int reaction, int role, int nb_type, int min_state, int max_state);
 /* integrator.RestrictReaction(...).define_connection(b1, b2)  reaction_setup.py:75-78,115-128 (group option
  * `connectivity_map`: a file of id pairs): reaction `reaction` only accepts candidate pairs whose unordered id pair was
  * defined; everything else about the reaction is unchanged.  Calls accumulate. */

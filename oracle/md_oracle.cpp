@@ -112,6 +112,8 @@ struct Orc {
   std::vector<chem_nb_change> nb_rules;   // PostProcessChangeNeighboursProperty
   std::map<std::pair<int32_t, int32_t>, uint32_t> restrict_map;   // RestrictReaction.define_connection: (tag lo, tag hi) -> reaction bits
   uint32_t restricted_mask = 0;
+  struct NbCons { int role = 0, nb_type = 0, min_state = 0, max_state = 0; };   // ReactionConstraintNeighbourState, per reaction
+  std::vector<NbCons> constraints;
   // integrator.ATRPActivator (reaction_post_process.py:380-426)
   struct AtrpCenter { int type, state, is_activator, new_type, delta_state; double new_mass, new_q; };
   bool atrp_on = false; chem_atrp_desc atrp{}; std::vector<AtrpCenter> atrp_centers; std::vector<chem_atrp_stats> atrp_stats;
@@ -622,6 +624,13 @@ static void react(Orc& o) {
       Vec3 d = minimg(o, o.x[a] - o.x[b]);
       double d2 = d.x * d.x + d.y * d.y + d.z * d.z;
       if (!(d2 >= R.min_cutoff * R.min_cutoff && d2 < R.cutoff * R.cutoff)) continue;
+      if (ri < o.constraints.size() && o.constraints[ri].role) {   // add_constraint(ReactionConstraintNeighbourState) (reaction_setup.py:203-204)
+        const Orc::NbCons& cs = o.constraints[ri];
+        const int32_t who = cs.role == 1 ? a : b;
+        bool ok_ = false;
+        for (int32_t nb : o.graph[who]) ok_ |= o.type[nb] == cs.nb_type && o.state[nb] >= cs.min_state && o.state[nb] < cs.max_state;
+        if (!ok_) continue;
+      }
       if ((o.restricted_mask >> ri) & 1u) {   // RestrictReaction: only the connections of the map (reaction_setup.py:115-128)
         auto it = o.restrict_map.find({lo, hi});
         if (it == o.restrict_map.end() || !((it->second >> ri) & 1u)) continue;
@@ -695,8 +704,9 @@ static void react(Orc& o) {
           std::sort(frontier.begin(), frontier.end());
           for (int32_t p : frontier) {
             if (o.type[p] != rl.old_type) continue;
+            if (rl.min_state < rl.max_state && !(o.state[p] >= rl.min_state && o.state[p] < rl.max_state)) continue;   // set_min_max_state
             o.type[p] = rl.new_type; o.mass[p] = rl.new_mass; o.q[p] = rl.new_q;
-            if (rl.set_state) o.state[p] = rl.new_state;
+            if (rl.set_state == 1) o.state[p] = rl.new_state; else if (rl.set_state == 2) o.state[p] += rl.new_state;   // incr_state
           }
         }
   }
@@ -952,6 +962,12 @@ int orc_reaction_neighbour_change(void* c, const chem_nb_change* r) {
   o.nb_rules.push_back(*r); return 0;
 }
 
+int orc_reaction_constraint(void* c, int reaction, int role, int nb_type, int min_state, int max_state) {
+  Orc& o = O(c);
+  if (reaction < 0 || reaction >= (int)o.reactions.size() || (role != 1 && role != 2) || nb_type < 0 || nb_type >= CHEM_MAX_TYPES) FAIL(CHEM_EINVAL, "reaction_constraint");
+  if (o.constraints.size() < o.reactions.size()) o.constraints.resize(o.reactions.size());
+  o.constraints[reaction] = Orc::NbCons{role, nb_type, min_state, max_state}; return 0;
+}
 int orc_reaction_restrict(void* c, int reaction, int64_t n, const int64_t* p) {
   Orc& o = O(c);
   if (reaction < 0 || reaction >= (int)o.reactions.size() || reaction >= 32) FAIL(CHEM_EINVAL, "reaction_restrict: reaction index");

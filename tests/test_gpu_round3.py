@@ -289,3 +289,22 @@ def test_restrict_reaction_matches_oracle(make_gpu, make_oracle):
     assert got and got <= {tuple(sorted(p)) for p in allowed.tolist()}
     assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
     assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+
+
+def test_exchange_reaction_matches_oracle(make_gpu, make_oracle):
+    """`A:B + C -> A:C + B` as the reference sets it up (reaction_setup.py:167-251): virtual A + C reaction, neighbour-state
+    constraint on A (bit table from the host's bond graph), the B neighbour retyped with its state incremented inside a
+    state window -- events, types and states against the oracle (fp64)."""
+    from test_oracle_extensions import _apply_exchange, _exchange_spec
+    spec = _exchange_spec(n_mol=1500, seed=33)
+    spec.setdefault("rebuild_criterion", 1)
+    g, o = make_gpu(64), make_oracle()
+    _apply_exchange(spec, g); _apply_exchange(spec, o)
+    for _ in range(3):
+        g.run(5); o.run(5)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    assert len(eo) > 100 and [e[:4] for e in eg] == [e[:4] for e in eo]
+    assert np.array_equal(g.get_state("TYPE"), o.get_state("TYPE"))
+    assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
+    assert (o.get_state("TYPE") == 3).sum() == len(eo)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8

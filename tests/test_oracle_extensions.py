@@ -172,3 +172,57 @@ def test_restrict_reaction_only_mapped_pairs_react(make_oracle):
     got = {tuple(sorted(p)) for p in np.stack([ev2["id_a"], ev2["id_b"]], 1)[ev2["reaction"] == 1].tolist()}
     assert got and got <= {tuple(sorted(p)) for p in allowed.tolist()}
     assert (ev2["reaction"] == 0).sum() > 0                                  # unrestricted reactions still fire
+
+
+def _exchange_spec(n_mol=300, seed=31):
+    """A-B dimers (bonded, B in state 0) in a bath of free C: the exchange `A(0,1):B(0,1) + C(0,1) -> A(1):C(1) + B(1)` as the
+    reference sets it up (reaction_setup.py:167-251): virtual A + C reaction, constraint "A carries a B in state [0,1)",
+    B neighbours of A in that window get B's new type / state + 1."""
+    rng = np.random.default_rng(seed)
+    A, B, C_, B2 = 0, 1, 2, 3
+    k = int(np.ceil((3 * n_mol) ** (1.0 / 3.0)))
+    a = 1.15
+    g = np.arange(k)
+    sites = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)[:3 * n_mol] * a + 0.5 * a
+    sites = sites + rng.uniform(-0.03, 0.03, sites.shape)
+    n = 3 * n_mol
+    types = np.tile(np.array([A, B, C_], np.int32), n_mol)          # neighbours along the fastest lattice axis: A B C A B C ...
+    ids = np.arange(1, n + 1)
+    bonds = np.stack([ids[0::3], ids[1::3]], 1)
+    return dict(n=n, box=[k * a] * 3, rc=2.5, skin=0.3, dt=0.002, ids=ids, types=types, pos=sites, vel=rng.normal(0, 0.3, (n, 3)),
+                mass=np.ones(n), state=np.zeros(n, np.int32), res_id=(np.arange(n) // 3 + 1).astype(np.int32),
+                lj=[(i, j, 0.3, 0.9, 2.5) for i in range(4) for j in range(i, 4)], kT=1.0, gamma=1.0, seed=seed,
+                lists=[dict(arity=2, kind="HARMONIC", params=[30.0, 1.15], ids=bonds)], exclusions=bonds,
+                reaction=dict(interval=5, nearest=True, seed=seed, bond=("HARMONIC", [30.0, 1.0]), type_mass={A: 1.0, B: 1.0, C_: 1.0, B2: 1.0},
+                              reactions=[dict(type_1=A, type_2=C_, min_state_1=0, max_state_1=1, min_state_2=0, max_state_2=1, delta_1=1, delta_2=1,
+                                              rate=1e9, cutoff=1.6, intramolecular=True, intraresidual=True, is_virtual=True)]))
+
+
+def _apply_exchange(spec, eng):
+    h = W.apply(spec, eng)
+    eng.reaction_constraint(0, "type_1", 1, 0, 1)                                   # A must carry a B in state [0, 1)
+    eng.reaction_neighbour_change(0, "type_1", 1, 1, 3, 1.0, incr_state=1, state_window=(0, 1))   # that B -> B2, state + 1
+    return h
+
+
+def test_exchange_reaction_constraint_and_incremented_neighbour(make_oracle):
+    spec = _exchange_spec()
+    o = make_oracle()
+    _apply_exchange(spec, o)
+    o.run(10)
+    ev = o.get_events()
+    assert len(ev) > 20
+    ty, st = o.get_state("TYPE"), o.get_state("STATE")
+    a_ids = ev["id_a"]                                            # role type_1 = A
+    assert np.all(spec["types"][a_ids - 1] == 0)
+    # every reacted A: state 1, its bonded B became B2 with state 1; unreacted dimers untouched
+    assert np.all(st[a_ids - 1] == 1) and np.all(ty[a_ids] == 3) and np.all(st[a_ids] == 1)
+    untouched = np.setdiff1d(spec["ids"][0::3], a_ids)
+    assert np.all(ty[untouched] == 1) and np.all(st[untouched] == 0)
+    assert len(np.unique(a_ids)) == len(a_ids)                    # an A that lost its B (state 1 now) cannot exchange again
+    # without the constraint partner (no bonds at all) nothing may react
+    spec2 = dict(spec, lists=[], exclusions=None)
+    o2 = make_oracle()
+    _apply_exchange(spec2, o2)
+    o2.run(10)
+    assert len(o2.get_events()) == 0
