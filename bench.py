@@ -152,7 +152,7 @@ def time_share(tm, steps):
 def load_traffic(n):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 cannot wrap itself inside bench.py):
     2 x FETCH_SIZE (gfx950 tallies 128-B read requests at 64 B) + WRITE_SIZE, tools/pmc_traffic.py."""
-    for name in ("round2_kernel_traffic.json", "round1_pair_traffic.json"):
+    for name in ("round3_kernel_traffic.json", "round2_kernel_traffic.json", "round1_pair_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             with open(path) as f:

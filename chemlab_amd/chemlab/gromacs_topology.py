@@ -390,6 +390,10 @@ def set_pair_interactions(espressopp, system, gt, lj_cutoff, dynamic_type_ids=()
             continue
         if prm and len(prm) > 2:
             sig, eps = float(prm[1]), float(prm[2])
+        elif not gt.gt.defaults.get("gen-pairs"):
+            # (the reference would look the pair up in gt.pairparams -- which nothing ever fills, :1337-1339 -- and then fail
+            #  on a missing key, :1345: without gen-pairs a pair line must carry its parameters)
+            raise RuntimeError("[ pairs ] entry %s-%s has no parameters and [ defaults ] gen-pairs is 'no'" % (a, b))
         else:
             s1, e1 = convertc6c12(at[n1]["sigma"], at[n1]["epsilon"], cr)
             s2, e2 = convertc6c12(at[n2]["sigma"], at[n2]["epsilon"], cr)

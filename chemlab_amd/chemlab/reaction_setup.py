@@ -156,6 +156,7 @@ class SetupReactions(object):
             inter = inter_class(self.system, fpl, pot)
             self.system.addInteraction(inter, "fpl_%s" % gname)
             self.fpls.append((gname, fpl, inter))
+            fpl.type_list = set()        # (type pairs, before and after, of the group's reactions: FPLDef.type_list, reaction_setup.py:436,532)
             for cr in group["reaction_list"]:
                 cr["connectivity_map"] = group.get("connectivity_map")      # group level -> reaction level (reaction_setup.py:488)
                 r = self._setup_reaction_exchange(cr, fpl) if cr.get("reaction_type") == "exchange" else self._setup_reaction_normal(cr, fpl)
@@ -163,4 +164,8 @@ class SetupReactions(object):
                     if name not in cr.get("exclude_extensions", []):
                         r.add_postprocess(pp, invoke_on)
                 ar.add_reaction(r)
+                n2t, rl = self.name2type, cr["reactant_list"]
+                second = "type_3" if cr.get("reaction_type") == "exchange" else "type_2"
+                fpl.type_list.add((n2t[rl["type_1"]["name"]], n2t[rl[second]["name"]]))
+                fpl.type_list.add((n2t[rl["type_1"]["new_type"]], n2t[rl[second]["new_type"]]))
         return ar, self.fpls

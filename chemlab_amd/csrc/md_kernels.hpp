@@ -2046,7 +2046,9 @@ __device__ __forceinline__ void bonded_term(const BondedParam& bp, const int me,
       else if (bp.kind == CHEM_POT_LJ_BOND) {   // FixedPairListLennardJones(epsilon, sigma, cutoff): 1-4 pairs
         if (r <= p[2]) {
           const double s2 = p[1] * p[1] / (r * r), s6 = s2 * s2 * s2;
-          u = 4.0 * p[0] * (s6 * s6 - s6);
+          // energy shifted to zero at the cutoff: espressopp's LennardJones defaults to shift = 'auto' (SURVEY App. C), also on the 1-4 lists
+          const double c2 = p[1] * p[1] / (p[2] * p[2]), c6 = p[2] < 1e29 ? c2 * c2 * c2 : 0.0;
+          u = 4.0 * p[0] * ((s6 * s6 - s6) - (c6 * c6 - c6));
           ff = 24.0 * p[0] * (2.0 * s6 * s6 - s6) / (r * r);
         }
       }

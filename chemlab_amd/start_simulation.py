@@ -68,10 +68,14 @@ def get_maximum_conversion(args, system, chem_fpls, gt):
     for o in args.maximum_conversion.split(","):
         sym, max_number, tot_number = o.split(":")
         max_number, tot_number = int(max_number), int(tot_number)
-        if "-" in sym:
+        if "-" in sym:          # the bond list of the group whose reactions involve this type pair (tools.py:128-138)
+            s1, s2 = re_ts.match(sym).groupdict()["type"].split("-")
+            t1, t2 = gt.used_atomsym_atomtype[s1], gt.used_atomsym_atomtype[s2]
             for _, fpl, _ in chem_fpls:
-                out.append((espressopp.analysis.NFixedPairListEntries(system, fpl), max_number))
-                break
+                tl = getattr(fpl, "type_list", None)
+                if tl is None or (t1, t2) in tl or (t2, t1) in tl:
+                    out.append((espressopp.analysis.NFixedPairListEntries(system, fpl), max_number))
+                    break
         elif "+" in sym:
             parts = []
             for ts in sym.split("+"):

@@ -375,7 +375,9 @@ static void bonded_forces(Orc& o) {
         } else if (l.kind == CHEM_POT_LJ_BOND) {   // FixedPairListLennardJones(epsilon, sigma, cutoff): 1-4 pairs
           if (r <= p[2]) {
             double s2 = p[1] * p[1] / (r * r), s6 = s2 * s2 * s2;
-            u = 4.0 * p[0] * (s6 * s6 - s6);
+            // shift = 'auto' (espressopp's LennardJones default): U(rc) = 0
+            double c2 = p[1] * p[1] / (p[2] * p[2]), c6 = p[2] < 1e29 ? c2 * c2 * c2 : 0.0;
+            u = 4.0 * p[0] * ((s6 * s6 - s6) - (c6 * c6 - c6));
             ff = 24.0 * p[0] * (2.0 * s6 * s6 - s6) / (r * r);
           }
         } else if (l.kind == CHEM_POT_TABULATED) {   // Tabulated(itype=1): linear interpolation, gromacs_topology.py:919-925

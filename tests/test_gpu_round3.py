@@ -308,3 +308,24 @@ def test_exchange_reaction_matches_oracle(make_gpu, make_oracle):
     assert np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
     assert (o.get_state("TYPE") == 3).sum() == len(eo)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_lj_14_pair_list_matches_oracle(make_gpu, make_oracle, prec):
+    """FixedPairListLennardJones (1-4 pairs): forces and the shifted list energy against the oracle."""
+    rng = np.random.default_rng(4)
+    n = 600
+    k = 9
+    pts = (np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 3)[:n] + 0.5) * 1.3
+    pos = pts + rng.uniform(-0.08, 0.08, pts.shape)
+    ids = np.arange(1, n + 1)
+    pairs = np.stack([ids[0:n - 1:2], ids[1:n:2]], 1)
+    spec = dict(n=n, box=[k * 1.3] * 3, rc=2.5, skin=0.3, dt=0.002, ids=ids, types=np.zeros(n, np.int32), pos=pos, vel=np.zeros((n, 3)),
+                mass=np.ones(n), lj=[(0, 0, 1.0, 1.0, 2.5)], kT=1.0, gamma=0.0, seed=1,
+                lists=[dict(arity=2, kind="LJ_BOND", params=[0.5, 1.05, 2.2], ids=pairs)], exclusions=pairs)
+    g, o, h = both(make_gpu, make_oracle, spec, prec, thermostat=False)
+    g.run(0); o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[prec]
+    og, oo = g.observe(), o.observe()
+    assert og["epot_list"][h[0]] == pytest.approx(oo["epot_list"][h[0]], rel=1e-11 if prec == 64 else 1e-5)
+    assert oo["epot_list"][h[0]] != 0.0

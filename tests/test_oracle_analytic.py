@@ -318,3 +318,26 @@ def test_svr_single_draw_matches_the_formula():
     k = 2.0 * lams ** 2          # K_new with instantaneous coupling: K_ref * chi^2(ndeg) / ndeg
     assert k.mean() == pytest.approx(2.0, rel=2e-3)
     assert k.std() / k.mean() == pytest.approx(np.sqrt(2.0 / 3000), rel=0.06)
+
+
+def test_lj_14_pair_list_closed_form_and_shift(make_oracle):
+    """FixedPairListLennardJones (1-4 pairs, gromacs_topology.py:1314-1411): the pair feels LJ through the list although it is
+    excluded from the non-bonded list; energy shifted to zero at the cutoff (espressopp's LennardJones default shift='auto')."""
+    eps, sig, rc, r = 0.7, 0.95, 2.0, 1.25
+    e = setup_small(make_oracle(), [[5, 5, 5], [5 + r, 5, 5]])
+    e.nb_lj(0, 0, 1.0, 1.0, 2.5, True)
+    e.set_exclusions([[1, 2]])
+    h = e.list_create(2, "LJ_BOND")
+    e.list_set_params(h, [eps, sig, rc])
+    e.list_add(h, [[1, 2]])
+    f, obs = forces_energy(e)
+    sr6, sc6 = (sig / r) ** 6, (sig / rc) ** 6
+    assert obs["epot_lj"] == 0.0
+    assert obs["epot_list"][h] == pytest.approx(4 * eps * ((sr6 ** 2 - sr6) - (sc6 ** 2 - sc6)), rel=1e-13)
+    assert f[1, 0] == pytest.approx(24 * eps * (2 * sr6 ** 2 - sr6) / r, rel=1e-13)
+    # beyond the list potential's own cutoff: nothing
+    e2 = setup_small(make_oracle(), [[5, 5, 5], [5 + 2.2, 5, 5]])
+    e2.nb_lj(0, 0, 1.0, 1.0, 2.5, True); e2.set_exclusions([[1, 2]])
+    h2 = e2.list_create(2, "LJ_BOND"); e2.list_set_params(h2, [eps, sig, rc]); e2.list_add(h2, [[1, 2]])
+    f2, obs2 = forces_energy(e2)
+    assert np.all(f2 == 0) and obs2["epot_list"][h2] == 0.0
