@@ -158,6 +158,8 @@ struct Ctx {
   double skin_eff() const { return skin_list > skin ? skin_list : skin; }
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
+  int opt_bucket_cap = 0;    // testing: bucket rows of the fused rebuild narrower than 64 (provokes the mid-run overflow recovery)
+  int64_t halts_recovered = 0;
   // slab domain decomposition (chem_comm_init)
   bool dd_on = false; int P = 1, rk = 0;
   std::unique_ptr<Transport> tr;
@@ -418,7 +420,7 @@ template <typename R> struct CtxT : Ctx {
     // bucket rows of the binning pass: 64 members per cell = what one wave sorts (the LDS tiles already require a mean
     // cell occupancy far below that); a fuller cell raises ctl->bucket_overflow and the unfused chain takes over
     cell_n.alloc(box.ncell + 1);
-    bcap = 64;
+    bcap = opt_bucket_cap > 0 ? std::min(opt_bucket_cap, 64) : 64;
     bucket.alloc((size_t)box.ncell * bcap);
     HIPCHK(hipMemsetAsync(bucket.p, 0, sizeof(int) * (size_t)box.ncell * bcap, stream));   // (the sort phase reads whole rows: entries must always be valid indices)
     if (!gbar.p) { gbar.alloc(1); HIPCHK(hipMemsetAsync(gbar.p, 0, sizeof(GridBar), stream)); }
@@ -452,6 +454,7 @@ template <typename R> struct CtxT : Ctx {
     a.par = fused_par; a.seg_shift = seg_shift; a.tseg_shift = tseg_shift; a.nblk = cdiv(n, kIntPerBlock); a.want32 = want32 ? 1 : 0; a.ntypes = ntypes; a.ablate = dbg_on ? opt_ablate_list : 0;
     a.half_skin = 0.5 * skin_eff(); a.rl2 = (R)((rc + skin_eff()) * (rc + skin_eff()));
     a.half_skin_ref = 0.5 * skin; a.rl2_rows = (R)((rc + skin) * (rc + skin));
+    a.istep = step;
     a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
     a.cell_cnt = cell_cnt.p; a.cell_of = cell_of.p; a.slot_of = slot_of.p; a.cell_start = cell_start.p; a.cell_loc = cell_loc.p;
@@ -991,7 +994,11 @@ template <typename R> struct CtxT : Ctx {
         // a cell more crowded than a bucket row: widen the rows up to what one wave sorts (64), beyond that this
         // system needs the unfused chain (its crowded-cell path ranks through global memory)
         set_ctl_field(&DevCtl::bucket_overflow, 0);
-        if (h.bucket_overflow <= 64 && bcap < 64) { bcap = 64; bucket.alloc((size_t)box.ncell * bcap); }
+        set_ctl_field(&DevCtl::halt, 0);       // (the launch that met the full row also stopped the run: this IS the recovery)
+        if (h.bucket_overflow <= 64 && bcap < 64) {
+          bcap = 64; bucket.alloc((size_t)box.ncell * bcap);
+          HIPCHK(hipMemsetAsync(bucket.p, 0, sizeof(int) * (size_t)box.ncell * bcap, stream));   // (the sort phase reads whole rows: entries must always be valid indices)
+        }
         else { use_fused = false; if (g_trace) fprintf(stderr, "[chem trace] cell with %d particles: fused rebuild off\n", h.bucket_overflow); }
         continue;
       }
@@ -1124,11 +1131,11 @@ template <typename R> struct CtxT : Ctx {
     // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
     const R cap = (cap_force > 0 && (with_lang || !lang)) ? (R)cap_force : (R)0;
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale());
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p);
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale());
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p);
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale());
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p);
   }
 
   void check_flags() {
@@ -1236,7 +1243,7 @@ template <typename R> struct CtxT : Ctx {
       tr->allreduce_sum_f64(resc_buf.p, 1, stream);
       hipLaunchKernelGGL(k_rescale_lambda, dim3(1), dim3(256), 0, stream, ekout.p, 0, resc_buf.p, resc_buf.p + 1, resc_kind, resc_kT, dt / resc_param, (double)nglob, svr_seed, (uint64_t)step);
     }
-    hipLaunchKernelGGL(k_scale_v<R>, dim3(nkb), dim3(256), 0, stream, G, n, v4.p, resc_buf.p + 1);
+    hipLaunchKernelGGL(k_scale_v<R>, dim3(nkb), dim3(256), 0, stream, G, n, v4.p, resc_buf.p + 1, (const DevCtl*)ctl.p);
   }
 
   // ---- the hot call -------------------------------------------------------------------
@@ -1269,13 +1276,31 @@ template <typename R> struct CtxT : Ctx {
     compute_forces();
     if (lang) launch_integrate<0>(true, true, step, 0);  // thermalize: f += friction + noise, stored
     bool need_int1 = true;
+    const int64_t step0 = step;
+    bool resume = false;       // re-entering the step at which the device stopped the run (DevCtl::halt)
+    // The device may stop an asynchronous run (fused rebuild: a cell outgrew its bucket row).  Every launch behind that
+    // point has left at once; the host learns of it at its next synchronisation -- a reaction / ATRP step or the end of
+    // the call --, repairs the set-up (wider rows or the unfused chain: rebuild_now) and re-enters the loop at that step.
+    auto halted = [&](int64_t& s) -> bool {
+      if (!use_fused) return false;
+      HIPCHK(hipStreamSynchronize(stream));
+      const DevCtl h = read_ctl();
+      if (!h.halt) return false;
+      s = h.halt_step - step0; step = h.halt_step;
+      set_ctl_field(&DevCtl::halt, 0);
+      resort = true; resume = true; need_int1 = false;
+      ++halts_recovered;
+      if (g_trace) fprintf(stderr, "[chem trace] run stopped by the device at step %lld (bucket rows of %d): recovering\n", (long long)h.halt_step, bcap);
+      return true;
+    };
     for (int64_t s = 0; s < nsteps; ++s) {
       if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
       timed_step = opt_time_pair && (pair_launch_no++ % opt_time_pair) == 0;
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
       const bool atrp_due = atrp_on && ((step + 1) % atrp.interval == 0);
       const bool last = (s == nsteps - 1);
-      if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
+      if (resume) { resume = false; rebuild_now(); compute_forces(); }   // (positions are drifted, forces of this step were never evaluated)
+      else if (dd_on) dd_step_sync();   // decision, (rebuild,) forces
       else { decide_and_rebuild(); compute_forces(); }
       resort = false;   // a rebuild requested by the last reaction step (force_rebuild on the device) has happened by now
 
@@ -1283,6 +1308,7 @@ template <typename R> struct CtxT : Ctx {
         launch_integrate<1>(lang, lang, step, 1);
         ++step;
         if (resc_kind == 1 || resc_kind == 3 || (resc_kind == 2 && step % (int64_t)resc_param == 0)) rescale_velocities();
+        if ((react_due || atrp_due || last) && halted(s)) { --s; continue; }   // (the loop's ++s lands on the stopped step)
         if (react_due) react_step();
         if (atrp_due) atrp_step();      // behind the reaction step: the driver adds the extension after `ar` (start_simulation.py:737-740)
         need_int1 = true;
@@ -2410,6 +2436,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "pair_block") { const int v = (int)value; REQUIRE(v == 256 || v == 512 || v == 1024, CHEM_EINVAL, "pair_block must be 256, 512 or 1024"); CTX.set_pair_bs(v); }
   else if (k == "ablate") CTX.opt_ablate = (int)value;
   else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; CTX.geom_dirty = true; }
+  else if (k == "bucket_cap") { CTX.opt_bucket_cap = (int)value; CTX.geom_dirty = true; }
   else if (k == "list_skin") { CTX.opt_list_skin = value; CTX.geom_dirty = true; CTX.resort = true; }
   else if (k == "debug_stamps") CTX.debug_enable((int)value);
   else if (k == "dd_self") {   // testing: one rank, ghost layers in z exchanged with itself by device copies
@@ -2434,6 +2461,8 @@ int64_t chem_debug_dump(chem_ctx* ctx, long long* out, int64_t cap) { return ctx
 // diagnostic: 8 int64 per workgroup of the last rebuilding k_rebuild_fused launch (phase stamps, tiles done)
 int64_t chem_debug_dump_rebuild(chem_ctx* ctx, long long* out, int64_t cap) { return ctx->c->debug_dump_rebuild(out, cap); }
 // diagnostic / tests: partner tags of the force list of particle `tag`, in list order; -1 without tiles
+// diagnostics / tests (unlisted, like chem_debug_force_list): how many times a run stopped by the device was resumed
+int64_t chem_debug_halts(chem_ctx* ctx) { return ctx && ctx->c ? ctx->c->halts_recovered : -1; }
 int64_t chem_debug_force_list(chem_ctx* ctx, int32_t tag, int32_t* out, int64_t cap) { try { return ctx->c->debug_force_list(tag, out, cap); } catch (...) { return -2; } }
 
 int chem_comm_unique_id(char uid[128]) {

@@ -67,6 +67,12 @@ struct DevCtl {
   // lists are rebuilt less often than that; forces do not depend on it (the force kernel applies the exact cutoff).
   int ref_rebuilds;
   double acc_ref;
+  // Recoverable stop of an asynchronous run: the fused rebuild met a cell fuller than a bucket row at step `halt_step`.  Every
+  // later launch of the run leaves at once (integrate, forces, bonded, rebuild), so the state stays "drifted, forces of
+  // halt_step not evaluated"; the host finds the flag at its next synchronisation, rebuilds with wider rows (or the unfused
+  // chain) and resumes at that step.
+  int halt, pad1;
+  long long halt_step;
 };
 
 template <typename R> struct Box {
@@ -209,7 +215,8 @@ template <typename R, int MODE, bool LANG, bool STOREF>
 __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
                                                     R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax,
-                                                    const Vec4<R>* __restrict__ x0, R cap, PosScale<R> ps) {
+                                                    const Vec4<R>* __restrict__ x0, R cap, PosScale<R> ps, const DevCtl* __restrict__ ctl) {
+  if (ctl->halt) return;   // (uniform scalar load; see DevCtl::halt)
   // kIntPerBlock particles per 256-thread block: every thread owns kIntPerBlock/256 particles and issues
   // all their loads before the first dependent instruction (more bytes in flight per wave for this
   // purely HBM-bound kernel); the arithmetic per particle is unchanged
@@ -1862,7 +1869,10 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
                                                    double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_,
                                                    DecideArgs da = DecideArgs{}) {
   constexpr bool LJONLY = MODE >= 1;
-  constexpr int NCH = TPP == 1 ? 3 : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
+#ifndef CHEM_NCH
+#define CHEM_NCH 3
+#endif
+  constexpr int NCH = TPP == 1 ? CHEM_NCH : (TPP == 2 ? 3 : 2);   // chunks (8 slots) each lane preloads before the staging barrier
   long long st0 = 0, st1 = 0, st2 = 0, st3 = 0;
   if (DIAG && dbg) st0 = wall_clock64();
   if (DIAG && ablate == 4) return;   // diagnostic: dispatch cost only
@@ -1883,6 +1893,7 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
     }
     if (need) return;
   } else if (guard && ctl->need_rebuild) return;   // speculative launch (decomposed path): the host rebuilds first and launches again
+  if (ctl->halt) return;
   __shared__ TileLDS<R> T;
   __shared__ PairCore<R> spc[kMaxTypes * kMaxTypes];
   CHEM_DYN_LDS(R);
@@ -1962,7 +1973,22 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
       };
 #pragma unroll
       for (int c = 0; c < NCH; ++c) if ((sub + c * TPP) * 8 < cnt) do_chunk(pkv[c]);
-      for (int c = sub + NCH * TPP; c * 8 < cnt; c += TPP) do_chunk(reg[(size_t)c * nhome + qq]);   // long rows
+      // rows longer than the preloaded chunks (the rule with a list skin: ~52 entries = 6.5 chunks): the load of the chunk
+      // after next is issued before a chunk is worked on, so that a lane waits for one L2 round trip per row, not per chunk
+      {
+        int c = sub + NCH * TPP;
+        bool have = c * 8 < cnt;
+        uint4 cur = make_uint4(0, 0, 0, 0);
+        if (have) cur = reg[(size_t)c * nhome + qq];
+        while (have) {
+          const int cn = c + TPP;
+          const bool hn = cn * 8 < cnt;
+          uint4 nx = make_uint4(0, 0, 0, 0);
+          if (hn) nx = reg[(size_t)cn * nhome + qq];
+          do_chunk(cur);
+          cur = nx; have = hn; c = cn;
+        }
+      }
     }
     if (TPP > 1) {
 #pragma unroll
@@ -2231,7 +2257,7 @@ template <typename R, bool BONDS_ONLY = false>
 __global__ __launch_bounds__(256) void k_bonded_work(const Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ f4, const int4* __restrict__ bwork, const int4* __restrict__ bj,
                                                      const BondedEntry* __restrict__ bent, const BondedParam* __restrict__ bpar, BoxD box, DevCtl* ctl, int guard, BTab bt) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= (int)(ctl->bw64 & 0xffffffffull) || (guard && ctl->need_rebuild)) return;
+  if (k >= (int)(ctl->bw64 & 0xffffffffull) || (guard && ctl->need_rebuild) || ctl->halt) return;
   const int4 wk = bwork[k];
   D3 f = {0, 0, 0};
   for (int e = wk.y; e < wk.y + wk.z; ++e) {
@@ -2306,6 +2332,7 @@ __device__ __forceinline__ bool grid_barrier(GridBar* gb, DevCtl* ctl) {
 template <typename R> struct FusedArgs {
   int n, ncell, ntiles, CAP, S, has_excl, criterion, par, seg_shift, tseg_shift, nblk, want32, ntypes, ablate;
   double half_skin; R rl2;
+  long long istep;                     // step this launch belongs to (recorded in ctl->halt_step when the launch has to stop the run)
   double half_skin_ref; R rl2_rows;    // the workload's skin: reference rebuild count, radius of the int32 Verlet rows (rl2 / half_skin: list skin)
   Vec4<R> *x4, *v4, *x4o, *v4o, *x0;
   int *tag, *tago, *rtag; int4 *img4, *img4o;
@@ -2376,6 +2403,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
   const int t = threadIdx.x, b = blockIdx.x, NB = gridDim.x, lane = lane_id(), w = t >> 6;
   DevCtl* const ctl = a.ctl;
 
+  if (ctl->halt) return;   // a previous launch of this run stopped it (set one launch ago at the earliest: every workgroup sees it)
   // ---- P0: decision, computed redundantly by every workgroup ----
   unsigned long long m = 0;
   for (int k = t; k < a.nblk; k += BS) { const unsigned long long v = a.blockmax[k]; m = v > m ? v : m; }
@@ -2418,7 +2446,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
     // host redoes this rebuild with the unfused chain (force_rebuild stays set)
     for (int k = b * BS + t; k < a.ncell; k += NB * BS) a.cell_cnt[k] = 0;
     if (b == 0) for (int k = t; k < 1024; k += BS) a.btot[k] = 0;
-    if (b == 0 && t == 0) { ctl->need_rebuild = 1; ctl->force_rebuild = 1; }
+    if (b == 0 && t == 0) { ctl->need_rebuild = 1; ctl->force_rebuild = 1; ctl->halt_step = a.istep; ctl->halt = 1; }
     return;
   }
   // every workgroup has taken its decision: the control block may change now
@@ -2635,7 +2663,8 @@ __global__ __launch_bounds__(256) void k_rescale_lambda(const double* __restrict
   }
 }
 template <typename R>
-__global__ __launch_bounds__(256) void k_scale_v(int i0, int n, Vec4<R>* __restrict__ v4, const double* __restrict__ lam) {
+__global__ __launch_bounds__(256) void k_scale_v(int i0, int n, Vec4<R>* __restrict__ v4, const double* __restrict__ lam, const DevCtl* __restrict__ ctl) {
+  if (ctl->halt) return;   // (a stopped run must not keep rescaling its frozen velocities)
   const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= i0 + n) return;
   const R s = (R)*lam;

@@ -329,3 +329,30 @@ def test_lj_14_pair_list_matches_oracle(make_gpu, make_oracle, prec):
     og, oo = g.observe(), o.observe()
     assert og["epot_list"][h[0]] == pytest.approx(oo["epot_list"][h[0]], rel=1e-11 if prec == 64 else 1e-5)
     assert oo["epot_list"][h[0]] != 0.0
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_run_stopped_by_the_device_recovers_and_changes_nothing(make_gpu, prec):
+    """A cell that outgrows its bucket row in the middle of an asynchronous run (fused rebuild): the device stops the run at
+    that step (every later launch leaves at once), the host finds out at its next synchronisation, widens the rows and
+    resumes there.  Provoked with rows of 33 slots (option bucket_cap) on a lattice start whose fullest cell holds 32: the
+    first builds fit, the melting system overflows a few dozen steps in.  The trajectory -- Langevin noise, reactions, bonds
+    -- must be bit-identical to an engine that never had to stop."""
+    spec = W.reactive_melt(n=8788, seed=71, interval=40)
+    spec["rebuild_criterion"] = 0
+    a, b = make_gpu(prec), make_gpu(prec)
+    ha, hb = W.apply(spec, a), W.apply(spec, b)
+    a.run(0)
+    tiles = a.get_state("POS")          # (initial occupancy: the same lattice for both)
+    L = spec["box"][0]; nc = int(L // 2.8)
+    occ = np.bincount(np.ravel_multi_index(np.minimum((tiles / (L / nc)).astype(int), nc - 1).T, (nc, nc, nc)), minlength=nc ** 3).max()
+    b.set_option("bucket_cap", int(occ) + 1)
+    a.run(120); b.run(120)
+    assert b.timers()["rebuilds"] == a.timers()["rebuilds"]
+    assert np.array_equal(a.get_state("POS_UNFOLDED"), b.get_state("POS_UNFOLDED"))
+    assert np.array_equal(a.get_state("VEL"), b.get_state("VEL"))
+    assert sorted_events(a.get_events()) == sorted_events(b.get_events()) and len(a.get_events()) > 100
+    assert np.array_equal(a.get_list(ha["reaction_bonds"]), b.get_list(hb["reaction_bonds"]))
+    lib = b.api.lib
+    lib.chem_debug_halts.restype = __import__("ctypes").c_int64
+    assert lib.chem_debug_halts(__import__("ctypes").c_void_p(b.ctx)) >= 1      # it did happen
