@@ -15,6 +15,8 @@ rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LD
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d $OUT/pmcB -- python3 $R/bench.py $S > $OUT/pmcB.json 2> $OUT/pmcB.err; echo "pmcB done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmcF -- python3 $R/bench.py $S > $OUT/pmcF.json 2> $OUT/pmcF.err; echo "pmcF done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmcW -- python3 $R/bench.py $S > $OUT/pmcW.json 2> $OUT/pmcW.err; echo "pmcW done"
+CHEM_TRACE=1 python3 $R/bench.py --steps 20 --warmup 5 --f64-steps 0 --cpu-steps 0 --late-stage 0 > $OUT/bench20.json 2> $OUT/bench20_trace.txt; echo "bench20 done"
+python3 $R/bench.py --steps 20 --warmup 5 --f64-steps 0 --cpu-steps 0 --late-stage 0 --no-roofline > $OUT/bench20_noroofline.json 2> /dev/null; echo "bench20 (no sampling) done"
 cd $R
 EQUIL=1500 python3 tools/tile_stamps.py 1000000 > $OUT/tile_stamps.txt 2>&1 || true
 python3 tools/kstats.py $(find $OUT/stats -name "*kernel_stats.csv" | head -1) 24 > $OUT/kernel_stats.txt
