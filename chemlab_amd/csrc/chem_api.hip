@@ -158,6 +158,7 @@ struct Ctx {
   double skin_eff() const { return skin_list > skin ? skin_list : skin; }
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
+  int opt_bonds_inline = 1;  // harmonic 2-body bonds evaluated by the force kernel from its staged image (when the host can prove it applicable)
   int opt_bucket_cap = 0;    // testing: bucket rows of the fused rebuild narrower than 64 (provokes the mid-run overflow recovery)
   int64_t halts_recovered = 0;
   // slab domain decomposition (chem_comm_init)
@@ -229,6 +230,31 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot, cell_n, bucket; int bcap = 0; DBuf<GridBar> gbar;
   DBuf<int> tile_cnt, tile_off;   // reaction scan on tiles: candidates per tile, their offsets
   DBuf<int4> bwork, bj; int nb_owner = 0; bool bwork_dirty = true;   // bonded work list (see dev_bonded_prep)
+  // Inline bonds: all bonded terms are 2-body bonds of ONE harmonic parameter set and the exclusion set is exactly the bond
+  // set (chain-growth systems) -> the LDS slots of the excluded partners, which the list build locates anyway, ARE the bonded
+  // partners: it writes them out (bslots), the force kernel evaluates the bonds from its staged image, the per-step bonded
+  // launch disappears.  Particles with more than kBondSlots (8) exclusions stay with the work list (then launched for them alone).
+  // Decided on the host from what it knows exactly (bonds_inline()).
+  DBuf<uint4> bslots; bool harmonic_only = false, bonds_excluded = false;
+  std::vector<uint8_t> excl_deg; size_t excl_deg_upto = 0; int64_t excl_over = 0;   // particles with more than kBondSlots (8) exclusions: their bonds stay with the work-list kernel
+  void update_excl_deg() {
+    if (excl_deg.size() != (size_t)top.n) { excl_deg.assign((size_t)top.n, 0); excl_deg_upto = 0; excl_over = 0; }
+    if (excl_deg_upto > top.excl_log.size()) { std::fill(excl_deg.begin(), excl_deg.end(), 0); excl_deg_upto = 0; excl_over = 0; }
+    for (; excl_deg_upto < top.excl_log.size(); ++excl_deg_upto) {
+      const auto& e = top.excl_log[excl_deg_upto];
+      for (int32_t t : {e.first, e.second}) { if (excl_deg[t] < 255) { ++excl_deg[t]; if (excl_deg[t] == kBondSlots + 1) ++excl_over; } }
+    }
+  }
+  double inline_K = 0, inline_r0 = 0;
+  bool bonds_inline() {
+    if (!opt_bonds_inline || !use_fused || dd_on || nbent <= 0 || !harmonic_only || !bonds_excluded) return false;
+    // the exclusion set must BE the bond set (bonds are a subset: bonds_excluded; both are duplicate-free): equal counts
+    size_t nb2 = 0;
+    for (const auto& l : top.lists) if (l.arity == 2) nb2 += (size_t)l.size();
+    if (nb2 != top.excl_log.size()) return false;
+    update_excl_deg();
+    return true;
+  }
   int fused_grid = 0, fused_grid_diag = 0, fused_par = 0, seg_shift = 0, tseg_shift = 0; bool use_fused = false;
   DBuf<int> nlist, nn, nnh;
   DBuf<unsigned short> nl16;
@@ -291,7 +317,10 @@ template <typename R> struct CtxT : Ctx {
   size_t ev_used = 0;
   std::vector<int> ev_kind;    // kind of sample k (events 2k, 2k+1): 0 pair, 1 neighbour kernel, 2 integrate, 3 bonded
   bool timed_step = false;
-  void tbeg(int kind) { if (timed_step && ev_used + 2 <= ev.size()) { HIPCHK(hipEventRecord(ev[ev_used], stream)); ev_kind.push_back(kind); } }
+  // A sampled step brackets the force kernel and ONE of the other per-step kernels (rotating) with events: the records between
+  // the launches cost ~3 us each, and eight of them on every sampled step showed in short timed regions
+  int timed_extra = 1;
+  void tbeg(int kind) { if (timed_step && (kind == 0 || kind == timed_extra) && ev_used + 2 <= ev.size()) { HIPCHK(hipEventRecord(ev[ev_used], stream)); ev_kind.push_back(kind); } }
   void tend() { if (timed_step && ev_used + 2 <= ev.size() && ev_kind.size() == ev_used / 2 + 1) { HIPCHK(hipEventRecord(ev[ev_used + 1], stream)); ev_used += 2; } }
 
   CtxT() { HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking)); }
@@ -464,6 +493,12 @@ template <typename R> struct CtxT : Ctx {
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
     a.wgst = dbg_on && wgst.p ? wgst.p : nullptr;
     a.bstart = bstart.p; a.bent = bent.p; a.bwork = bwork.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
+    a.bslots = nullptr;
+    if (bonds_inline() && !(sizeof(R) == 8 && want32)) {   // (the exact fp64 builder of the int32 rows locates no slots: ensure_list32 rebuilds again)
+      if (bslots.n < 2 * (size_t)n) bslots.alloc(2 * (size_t)n + 1024);      // two quads (kBondSlots = 8 words) per home particle
+      a.bslots = bslots.p;
+      if (excl_over == 0) a.nbent = 0;                      // no work list needed; otherwise it holds the owners with > 4 exclusions only
+    }
     if (dbg_on || want32) hipLaunchKernelGGL((k_rebuild_fused<R, 512, true>), dim3(fused_grid_diag), dim3(512), list_lds_need(true), stream, a);
     else hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), list_lds_need(false), stream, a);
     fused_par ^= 1;
@@ -693,6 +728,20 @@ template <typename R> struct CtxT : Ctx {
     // analytic pair terms only (the chain-growth systems): the per-step kernel without the angle / dihedral / table code
     bonds_only = nslot > 0;
     for (const auto& q : hp) bonds_only &= q.arity == 2 && (q.kind == CHEM_POT_HARMONIC || q.kind == CHEM_POT_FENE || q.kind == CHEM_POT_FENE_LJ || q.kind == CHEM_POT_LJ_BOND);
+    harmonic_only = nslot == 1 && hp[0].arity == 2 && hp[0].kind == CHEM_POT_HARMONIC;      // ONE harmonic parameter set (kernel arguments of the force launch)
+    if (harmonic_only) { inline_K = hp[0].p[0]; inline_r0 = hp[0].p[1]; }
+    if (full && harmonic_only) {
+      // every listed pair must be an excluded pair (ChemLab's DynamicExcludeList observes the bond lists; a caller of the C ABI
+      // need not): checked once against the host's exclusion rows; bonds made by reactions are excluded by construction
+      bonds_excluded = true;
+      for (const auto& l : top.lists) {
+        if (l.arity != 2) continue;
+        for (size_t e = 0; e < (size_t)l.size() && bonds_excluded; ++e) {
+          const int32_t a_ = l.ent[2 * e], b_ = l.ent[2 * e + 1];
+          bonds_excluded = std::binary_search(top.excl[a_].begin(), top.excl[a_].end(), b_);
+        }
+      }
+    }
     bpar.alloc(std::max<size_t>(hp.size(), 1)); skeys.alloc(std::max<size_t>(hk.size(), 1));
     if (nslot) {
       HIPCHK(hipMemcpyAsync(bpar.p, hp.data(), hp.size() * sizeof(BondedParam), hipMemcpyHostToDevice, stream));
@@ -1057,6 +1106,7 @@ template <typename R> struct CtxT : Ctx {
 
   template <bool ENERGY> int launch_pair(V4* fdst, int tpp) {
     const double hs = 0.5 * skin_eff();
+    const bool inline_now = bonds_inline();
     if (use_tiles) {
       // which tiles: all (default), or the interior / boundary subset of a slab (see TileSub)
       const int ntxy = ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY);
@@ -1066,7 +1116,8 @@ template <typename R> struct CtxT : Ctx {
       else if (pair_subset == 2) { ts = TileSub{0, ntxy, ntiles - ntxy}; nsub = 2 * ntxy; }
       if (nsub <= 0) return 0;
 #define LTD(T, M, B, D) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M, D>), dim3(nsub), dim3(B), pair_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
-                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, pair_guard, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr, ts, pair_da)
+                                 nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, pair_guard, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr, ts, pair_da, \
+                                 (!ENERGY && inline_now) ? (const uint4*)bslots.p : (const uint4*)nullptr, inline_K, inline_r0)
 #define LT(T, M, B) LTD(T, M, B, false)
       // diagnostics (options debug_stamps / ablate): one instantiation, one lane per particle, 512 threads
 #define LTB(T, M) do { if ((dbg_on || opt_ablate) && !ENERGY) { if (T != 1 || pair_bs != 512) throw ChemError(CHEM_EINVAL, "debug_stamps / ablate need tpp=1 and pair_block=512"); LTD(1, M, 512, true); } \
@@ -1101,16 +1152,21 @@ template <typename R> struct CtxT : Ctx {
     if (timed) tend();
     pair_subset = 0;
     if (subset == 1) { pair_guard = 0; return; }   // interior tiles only: bonded terms follow with the boundary launch
-    if (nbent > 0 && (use_fused || dd_on)) {
+    const bool inl = nbent > 0 && bonds_inline();
+    if (inl && excl_over == 0) {
+      // harmonic bonds were evaluated by the force kernel (inline bonds): no bonded launch
+    } else if (nbent > 0 && (use_fused || dd_on)) {
       // work-list kernel: owners only, partner indices resolved at the last rebuild
       if (bwork_dirty) {   // bonded lists changed without a rebuild since
         HIPCHK(hipMemsetAsync(&ctl.p->bw64, 0, sizeof(unsigned long long), stream));
-        hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p);
+        hipLaunchKernelGGL(k_bonded_prep, dim3(std::max(1, std::min(cdiv(n, 256), 1024))), dim3(256), 0, stream, G, n, tag.p, rtag.p, bstart.p, bent.p, bwork.p, bj.p, ctl.p,
+                           inl ? (const int*)excl_start.p : (const int*)nullptr);
         bwork_dirty = false;
       }
       if (timed) tbeg(3);
-      if (bonds_only) hipLaunchKernelGGL((k_bonded_work<R, true>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
-      else hipLaunchKernelGGL((k_bonded_work<R, false>), dim3(cdiv(nb_owner, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
+      const int nown = inl ? (int)std::min<int64_t>(nb_owner, excl_over) : nb_owner;   // (inline bonds: the list holds the owners with > kBondSlots exclusions only)
+      if (bonds_only) hipLaunchKernelGGL((k_bonded_work<R, true>), dim3(cdiv(nown, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
+      else hipLaunchKernelGGL((k_bonded_work<R, false>), dim3(cdiv(nown, 256)), dim3(256), 0, stream, x4.p, f4.p, bwork.p, bj.p, bent.p, bpar.p, boxd, ctl.p, speculative ? 1 : 0, btab_view());
       if (timed) tend();
     } else if (nbent > 0)
       hipLaunchKernelGGL((k_bonded<R, false>), dim3(cdiv(n, 256)), dim3(256), 0, stream, G, n, x4.p, f4.p, tag.p, rtag.p, bstart.p, bent.p,
@@ -1154,6 +1210,7 @@ template <typename R> struct CtxT : Ctx {
     if (h.nl_overflow) throw ChemError(CHEM_ENOSPC, "neighbour row overflow during run: needed " + std::to_string(h.nl_overflow) + ", capacity " + std::to_string(S) + " (chem_set_nlist_capacity)");
     if (h.skin_violation) throw ChemError(CHEM_ESTATE, "internal: neighbour list used past skin/2");
     if (h.excl_slot_error) throw ChemError(CHEM_ESTATE, "internal: list build could not locate an excluded partner in its cell");
+    if (h.bond_slot_miss) throw ChemError(CHEM_ESTATE, "internal: inline bonds enabled for a system with a bonded partner outside the located exclusions (set option bonds_inline=0)");
     if (h.barrier_timeout) throw ChemError(CHEM_ESTATE, "fused rebuild: grid barrier timed out (device shared with another job?); set option fused_rebuild=0");
     if (h.bucket_overflow) throw ChemError(CHEM_ENOSPC, "a cell filled up with " + std::to_string(h.bucket_overflow) + " particles during the run (fused rebuild bucket rows hold " + std::to_string(bcap) + "); set option fused_rebuild=0");
     if (h.cand_overflow) throw ChemError(CHEM_ENOSPC, "reaction candidate buffer overflow");
@@ -1296,6 +1353,7 @@ template <typename R> struct CtxT : Ctx {
     for (int64_t s = 0; s < nsteps; ++s) {
       if (need_int1) { launch_integrate<2>(false, false, step, 1); need_int1 = false; }
       timed_step = opt_time_pair && (pair_launch_no++ % opt_time_pair) == 0;
+      if (timed_step) timed_extra = 1 + (int)((pair_launch_no / opt_time_pair) % 3);
       const bool react_due = react_on && interval > 0 && ((step + 1) % interval == 0);
       const bool atrp_due = atrp_on && ((step + 1) % atrp.interval == 0);
       const bool last = (s == nsteps - 1);
@@ -1355,6 +1413,7 @@ template <typename R> struct CtxT : Ctx {
     want32 = true;
     rebuild_now();
     want32 = false;
+    if (sizeof(R) == 8 && bonds_inline()) rebuild_now();   // same order, same rows; the regular builder records the bonded partners' slots again
   }
 
   // ---- reactions ----------------------------------------------------------------------
@@ -2436,6 +2495,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "pair_block") { const int v = (int)value; REQUIRE(v == 256 || v == 512 || v == 1024, CHEM_EINVAL, "pair_block must be 256, 512 or 1024"); CTX.set_pair_bs(v); }
   else if (k == "ablate") CTX.opt_ablate = (int)value;
   else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; CTX.geom_dirty = true; }
+  else if (k == "bonds_inline") { CTX.opt_bonds_inline = value != 0; CTX.resort = true; }
   else if (k == "bucket_cap") { CTX.opt_bucket_cap = (int)value; CTX.geom_dirty = true; }
   else if (k == "list_skin") { CTX.opt_list_skin = value; CTX.geom_dirty = true; CTX.resort = true; }
   else if (k == "debug_stamps") CTX.debug_enable((int)value);

@@ -71,9 +71,15 @@ struct DevCtl {
   // later launch of the run leaves at once (integrate, forces, bonded, rebuild), so the state stays "drifted, forces of
   // halt_step not evaluated"; the host finds the flag at its next synchronisation, rebuilds with wider rows (or the unfused
   // chain) and resumes at that step.
-  int halt, pad1;
+  int halt;
+  int bond_slot_miss;                 // list build: a bonded partner was not among the located excluded partners (internal: the host only enables inline bonds when it cannot happen)
   long long halt_step;
 };
+
+// bonded tables (per-tag CSR, see K4-K6 below; declared here because the list build records the LDS slots of bonded partners)
+constexpr int kBondSlots = 8;   // inline bonds: recorded partner slots per home particle (two 16-byte quads)
+struct BondedEntry { int t0, t1, t2, meta; };   // tuple tags in order (self included); meta = slot | mypos<<28; quadruples use a 2nd entry for t3
+struct BondedParam { int kind, list, arity, pad; double p[CHEM_MAX_POT_PARAMS]; };
 
 template <typename R> struct Box {
   R L[3], invL[3];
@@ -1550,7 +1556,8 @@ template <typename RS, int BS>
 __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigned char* lds, const ListLDS& L, const int* tag, const float rl2,
                                                    const int* excl_start, const int* excl_list, const int has_excl,
                                                    unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl,
-                                                   const Box<RS>* bx, const int* rtag, const Vec4<RS>* x4, const int ablate = 0, const float rl2_rows_ = -1.f) {
+                                                   const Box<RS>* bx, const int* rtag, const Vec4<RS>* x4, const int ablate = 0, const float rl2_rows_ = -1.f,
+                                                   uint4* bslots = nullptr) {
   const float rl2_rows = rl2_rows_ > 0.f ? rl2_rows_ : rl2;   // int32 Verlet rows: the workload's rc+skin (the 16-bit force list may use a wider list skin)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1614,6 +1621,26 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
         }
         if (k == 0) xs0 = slot; else if (k == 1) xs1 = slot; else if (k == 2) xs2 = slot; else xs3 = slot;
       }
+    }
+    // Inline bonds (force kernel epilogue).  The host enables this only where the exclusion set IS the bond set and all bonds
+    // share one harmonic parameter set (chain-growth systems: every reaction bond is excluded, nothing else is): the LDS slots
+    // of the excluded partners are the bonded partners -- recorded as they are (eight 32-bit words per home particle, ~0 = none),
+    // no bonded table is consulted.  Located partners (<= 4 exclusions) are written here; on the generic path (5..8 exclusions,
+    // or int32 rows wanted) every excluded hit is recorded as it is met in the sweep below.  More than kBondSlots exclusions:
+    // the particle's bonds stay with the work list.
+    unsigned int* const bsw = bslots ? reinterpret_cast<unsigned int*>(bslots) + (size_t)(hbase + q) * kBondSlots : nullptr;
+    int nbw = 0;
+    const bool bond_rec = bsw && !fastx && e1 > e0 && e1 - e0 <= kBondSlots;      // generic path records while sweeping
+    if (bsw && (fastx || e1 == e0)) {
+      uint4 bw = make_uint4(~0u, ~0u, ~0u, ~0u);
+      if (fastx) {
+        if (xs0 >= 0) bw.x = (unsigned int)xs0; else if (e0 + 0 < e1) ctl->bond_slot_miss = 1;
+        if (xs1 >= 0) bw.y = (unsigned int)xs1; else if (e0 + 1 < e1) ctl->bond_slot_miss = 1;
+        if (xs2 >= 0) bw.z = (unsigned int)xs2; else if (e0 + 2 < e1) ctl->bond_slot_miss = 1;
+        if (xs3 >= 0) bw.w = (unsigned int)xs3; else if (e0 + 3 < e1) ctl->bond_slot_miss = 1;
+      }
+      *reinterpret_cast<uint4*>(bsw) = bw;
+      if (bw.w != ~0u) *reinterpret_cast<uint4*>(bsw + 4) = make_uint4(~0u, ~0u, ~0u, ~0u);   // (the second quad is only read behind a full first one)
     }
     const bool plain = (e1 == e0 || fastx) && !row32;
     uint4* regq = reinterpret_cast<uint4*>(reg16) + q;   // chunk c of this particle: regq[c * nhome]
@@ -1731,6 +1758,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
             if (e1 > e0) {
               const int tgj = tag[j];
               for (int ee = e0; ee < e1; ++ee) if (excl_list[ee] == tgj) { ok = false; break; }
+              if (!ok && bond_rec && nbw < kBondSlots) bsw[nbw++] = (unsigned int)sl;      // inline bonds: an excluded hit is a bonded partner
             }
             if (ok) {
               if (tm & bit) push((unsigned int)sl);      // (shell pairs included, as on the plain path: the force list does not depend on the path)
@@ -1739,6 +1767,10 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
           }
         }
       }
+    }
+    if (bsw && !fastx && e1 > e0) {       // generic path: close the record (or leave it empty for a particle the work list keeps)
+      if (bond_rec && nbw != e1 - e0) ctl->bond_slot_miss = 1;      // every excluded (= bonded) partner sits within the list radius
+      for (int k = bond_rec ? nbw : 0; k < kBondSlots; ++k) bsw[k] = ~0u;
     }
     // pad the last chunk with the far-away dummy slot (chunks are read whole)
     const int real16 = cnt16;
@@ -1867,7 +1899,8 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
                                                    int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
                                                    double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_,
-                                                   DecideArgs da = DecideArgs{}) {
+                                                   DecideArgs da = DecideArgs{}, const uint4* __restrict__ bslots = nullptr,
+                                                   double bond_K = 0.0, double bond_r0 = 0.0) {
   constexpr bool LJONLY = MODE >= 1;
 #ifndef CHEM_NCH
 #define CHEM_NCH 3
@@ -1915,6 +1948,7 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
   // overlaps the stencil loads
   int p = -1, cnt = 0, hslot = 0, qq = 0;
   uint4 pkv[NCH];
+  uint4 bwv = make_uint4(~0u, ~0u, ~0u, ~0u);
   auto locate = [&](int q) {
     int sgi = 0;
 #pragma unroll
@@ -1924,6 +1958,7 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
     const int hr = (sgi / HY + 1) * SY + (sgi % HY + 1);
     hslot = T.rowoff[hr] + T.celloff[hr][1] + inrun;      // the home particle's own slot in the staged tile
     cnt = nnh[hbase + q];
+    if (!ENERGY && bslots) bwv = bslots[2 * (size_t)(hbase + q)];   // (inline bonds: first quad, issued with the list chunks, consumed after the pair loop)
 #pragma unroll
     for (int c = 0; c < NCH; ++c)                           // the tile's region is always allocated: safe before cnt is known
       pkv[c] = (sub + c * TPP) * 8 < S16 ? nt_load_u4(&reg[(size_t)(sub + c * TPP) * nhome + q]) : make_uint4(0, 0, 0, 0);
@@ -1943,8 +1978,48 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
       Vec4<R> xi;
       if constexpr (D3) { xi = lds_gather3d(sx, hslot); xi.w = (R)d3_types<R>(sx, CAP)[hslot]; } else xi = sx[hslot];
       const int pbase = (int)xi.w * ntypes;
+      // Uniform-LJ fp32 path: (x, y) of one neighbour live in an aligned register pair (the 16-byte LDS read returns
+      // x y z w in four consecutive VGPRs), so the differences, their squares and the force accumulation of the x and y
+      // components are PACKED fp32 instructions on that pair -- no register shuffling as when the compiler pairs up two
+      // neighbours (its SLP form of this loop spent 27.6 VALU instructions per neighbour, profiles/round3_pmc_sq_counters.txt)
+      typedef float f32x2_ __attribute__((ext_vector_type(2)));
+      typedef float f32x4_ __attribute__((ext_vector_type(4)));
+      f32x2_ fxy = {0.f, 0.f};
+      [[maybe_unused]] const f32x2_ xixy = {(float)xi.x, (float)xi.y};
       auto do_chunk = [&](const uint4 pk) {
         const unsigned int wds[4] = {pk.x, pk.y, pk.z, pk.w};
+#ifndef CHEM_PK
+#define CHEM_PK 1
+#endif
+        if constexpr (CHEM_PK && MODE == 2 && !ENERGY && sizeof(R) == 4) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4_ pj[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // 4 LDS gathers in flight
+              const unsigned int sl = (wds[2 * h + (u >> 1)] >> ((u & 1) * 16)) & 0xffff;
+              pj[u] = *((const volatile __attribute__((address_space(3))) f32x4_*)sx + sl);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {      // two neighbours: distances per neighbour on its (x, y) pair, the LJ chain packed over the two
+              const f32x2_ dxy0 = xixy - pj[u].xy, dxy1 = xixy - pj[u + 1].xy;
+              const float dz0 = (float)xi.z - pj[u].z, dz1 = (float)xi.z - pj[u + 1].z;
+              const f32x2_ sq0 = dxy0 * dxy0, sq1 = dxy1 * dxy1;
+              const f32x2_ r2 = {__builtin_fmaf(dz0, dz0, sq0.x + sq0.y), __builtin_fmaf(dz1, dz1, sq1.x + sq1.y)};
+              const f32x2_ r2i = {__builtin_amdgcn_rcpf(r2.x), __builtin_amdgcn_rcpf(r2.y)};
+              const f32x2_ r6i = r2i * r2i * r2i;
+              const f32x2_ lj1v = {(float)u_lj1, (float)u_lj1}, lj2v = {-(float)u_lj2, -(float)u_lj2};
+              f32x2_ ff = r6i * __builtin_elementwise_fma(lj1v, r6i, lj2v) * r2i;
+              ff.x = (r2.x <= (float)u_rc2) ? ff.x : 0.f;
+              ff.y = (r2.y <= (float)u_rc2) ? ff.y : 0.f;
+              const f32x2_ f0 = {ff.x, ff.x}, f1 = {ff.y, ff.y};
+              fxy = __builtin_elementwise_fma(f0, dxy0, fxy);
+              fxy = __builtin_elementwise_fma(f1, dxy1, fxy);
+              fz = (R)__builtin_fmaf(ff.y, dz1, __builtin_fmaf(ff.x, dz0, (float)fz));
+            }
+          }
+          return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           Vec4<R> xs[4];
@@ -1989,6 +2064,29 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
           cur = nx; have = hn; c = cn;
         }
       }
+      fx += (R)fxy.x; fy += (R)fxy.y;      // (packed x/y accumulators of the uniform-LJ fp32 path; zero otherwise)
+      if (!ENERGY && bslots) {
+        // Inline harmonic bonds (FixedPairListHarmonic, gromacs_topology.py:949-961; reaction bonds reaction_setup.py:449-467):
+        // the partners' LDS slots were recorded by the list build, the geometry comes from the staged image (tile-local
+        // coordinates: 2.4e-7 in the fp32 build, exact in fp64) -- no bonded launch, no second pass over f4
+        const R m2K = (R)(-2.0 * bond_K), r0b = (R)bond_r0;              // (one parameter set: kernel arguments, no table)
+        auto bond_quad = [&](const uint4 bq) {
+          const unsigned int bws[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (bws[k] == ~0u) continue;
+            const unsigned int sl = bws[k];
+            Vec4<R> xj;
+            if constexpr (D3) xj = lds_gather3d(sx, sl); else xj = sx[sl];
+            const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
+            const R r = sqrt_r(dx * dx + dy * dy + dz * dz);
+            const R ffb = m2K * (r - r0b) / r;                             // U = K (r - r0)^2
+            fx += ffb * dx; fy += ffb * dy; fz += ffb * dz;
+          }
+        };
+        bond_quad(bwv);
+        if (bwv.w != ~0u) bond_quad(bslots[2 * (size_t)(hbase + qq) + 1]);   // five to eight bonds: the second quad (rare)
+      }
     }
     if (TPP > 1) {
 #pragma unroll
@@ -2020,8 +2118,6 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
 //     member of a tuple evaluates the term and keeps its own force -> no atomics,
 //     deterministic.  Geometry in fp64 in both precision modes.
 // =======================================================================================
-struct BondedEntry { int t0, t1, t2, meta; };   // tuple tags in order (self included); meta = slot | mypos<<28; quadruples use a 2nd entry for t3
-struct BondedParam { int kind, list, arity, pad; double p[CHEM_MAX_POT_PARAMS]; };
 
 __device__ __forceinline__ D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
@@ -2216,13 +2312,18 @@ __device__ __forceinline__ int block_scan_excl(int v, int* total) {
 // much as a full one), and has two dependent loads in front of the arithmetic instead of five.
 // one chunk of BS particles starting at ib (block-uniform; ends with a workgroup barrier)
 template <int BS>
+// over_excl != nullptr (inline bonds): only the owners with MORE than kBondSlots exclusions enter the work list -- the force kernel
+// evaluates the bonds of everybody else from its staged image (excl_start rows: the same criterion the list build applies)
 __device__ __forceinline__ void dev_bonded_prep_chunk(int ib, int iend, const int* tag, const int* rtag, const int* bstart, const BondedEntry* bent,
-                                                      int4* bwork, int4* bj, DevCtl* ctl) {
+                                                      int4* bwork, int4* bj, DevCtl* ctl, const int* over_excl = nullptr) {
   __shared__ int s_base, s_ebase;
   {
     const int i = ib + threadIdx.x;
     int e0 = 0, e1 = 0;
-    if (i < iend) { const int tg = tag[i]; e0 = bstart[tg]; e1 = bstart[tg + 1]; }
+    if (i < iend) {
+      const int tg = tag[i]; e0 = bstart[tg]; e1 = bstart[tg + 1];
+      if (over_excl && over_excl[tg + 1] - over_excl[tg] <= kBondSlots) e1 = e0;
+    }
     const int has = e1 > e0 ? 1 : 0;
     int tot, etot;
     const int rank = block_scan_excl<BS>(has, &tot);       // one global atomic per block and pass, not per wave:
@@ -2243,14 +2344,15 @@ __device__ __forceinline__ void dev_bonded_prep_chunk(int ib, int iend, const in
 }
 template <int BS>
 __device__ __forceinline__ void dev_bonded_prep(int i0, int n, const int* tag, const int* rtag, const int* bstart, const BondedEntry* bent,
-                                                int4* bwork, int4* bj, DevCtl* ctl) {
+                                                int4* bwork, int4* bj, DevCtl* ctl, const int* over_excl = nullptr) {
   for (int ib = i0 + blockIdx.x * BS; ib < i0 + n; ib += gridDim.x * BS)    // block-uniform bound (block scan inside)
-    dev_bonded_prep_chunk<BS>(ib, i0 + n, tag, rtag, bstart, bent, bwork, bj, ctl);
+    dev_bonded_prep_chunk<BS>(ib, i0 + n, tag, rtag, bstart, bent, bwork, bj, ctl, over_excl);
 }
 
 __global__ __launch_bounds__(256) void k_bonded_prep(int i0, int n, const int* __restrict__ tag, const int* __restrict__ rtag, const int* __restrict__ bstart,
-                                                     const BondedEntry* __restrict__ bent, int4* __restrict__ bwork, int4* __restrict__ bj, DevCtl* ctl) {
-  dev_bonded_prep<256>(i0, n, tag, rtag, bstart, bent, bwork, bj, ctl);
+                                                     const BondedEntry* __restrict__ bent, int4* __restrict__ bwork, int4* __restrict__ bj, DevCtl* ctl,
+                                                     const int* __restrict__ over_excl) {
+  dev_bonded_prep<256>(i0, n, tag, rtag, bstart, bent, bwork, bj, ctl, over_excl);
 }
 
 template <typename R, bool BONDS_ONLY = false>
@@ -2346,6 +2448,7 @@ template <typename R> struct FusedArgs {
   unsigned short* nl16; int *nnh, *nlist, *nn;
   unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
   const int* bstart; const BondedEntry* bent; int4 *bwork, *bj; int nbent;
+  uint4* bslots;         // inline bonds (non-null: the list build records the bonded partners' LDS slots, no work list is built)
   Box<R> box; ActMask act;
   long long* wgst;   // diagnostics (option debug_stamps=2): 8 wall-clock stamps per workgroup of the last rebuilding launch
 };
@@ -2554,7 +2657,8 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
         if (ablate == 1) { for (int q = t; q < T.geom[4]; q += BS) a.nnh[T.geom[5] + q] = 0; }
         else
         dev_nlist_tile_f32<R, BS>(T, chem_dyn_lds, L, a.tago, (float)a.rl2, a.excl_start, a.excl_list, a.has_excl, a.nl16, a.S, a.nnh,
-                               (DIAG && a.want32) ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, ablate, (float)a.rl2_rows);
+                               (DIAG && a.want32) ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, ablate, (float)a.rl2_rows,
+                               a.bslots);
       } else {
         tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
         __syncthreads();
@@ -2601,7 +2705,7 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
         __syncthreads();
         const int ib = s_tile * BS;
         if (ib >= a.n) break;
-        dev_bonded_prep_chunk<BS>(ib, a.n, a.tago, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl);
+        dev_bonded_prep_chunk<BS>(ib, a.n, a.tago, a.rtag, a.bstart, a.bent, a.bwork, a.bj, ctl, a.bslots ? a.excl_start : (const int*)nullptr);
       }
     }
     // copy-back (+ reference positions): every workgroup moves its share once it has no tile left

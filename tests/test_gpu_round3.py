@@ -356,3 +356,73 @@ def test_run_stopped_by_the_device_recovers_and_changes_nothing(make_gpu, prec):
     lib = b.api.lib
     lib.chem_debug_halts.restype = __import__("ctypes").c_int64
     assert lib.chem_debug_halts(__import__("ctypes").c_void_p(b.ctx)) >= 1      # it did happen
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_inline_bonds_equal_the_bonded_kernel(make_gpu, make_oracle, prec):
+    """Harmonic bonds evaluated in the force kernel's epilogue from its staged image (partner LDS slots recorded by the list
+    build; no bonded launch) against the per-step bonded kernel and the oracle, on a reacting system whose bonds, exclusions
+    and list rebuilds keep changing."""
+    spec = W.reactive_melt(n=8788, seed=81, interval=10)
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e9
+    a, b, o = make_gpu(prec), make_gpu(prec), make_oracle()
+    ha, hb, ho = W.apply(spec, a), W.apply(spec, b), W.apply(spec, o)
+    b.set_option("bonds_inline", 0)
+    for _ in range(4):
+        a.run(10); b.run(10); o.run(10)
+    assert len(o.get_events()) > 2000 and len(o.get_list(ho["reaction_bonds"])) > 300
+    fa, fb, fo = a.get_state("FORCE"), b.get_state("FORCE"), o.get_state("FORCE")
+    if prec == 64:
+        assert [e[:4] for e in sorted_events(a.get_events())] == [e[:4] for e in sorted_events(o.get_events())]
+        assert np.array_equal(a.get_list(ha["reaction_bonds"]), o.get_list(ho["reaction_bonds"]))
+        assert rel_err(a.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+        assert rel_err(a.get_state("POS_UNFOLDED"), b.get_state("POS_UNFOLDED")) < 1e-9
+    else:
+        assert rel_err(a.get_state("POS_UNFOLDED"), b.get_state("POS_UNFOLDED")) < 1e-4
+    # a static comparison on one and the same configuration (the trajectories above have drifted apart by rounding)
+    spec2 = dict(spec, pos=a.get_state("POS"), vel=a.get_state("VEL"), types=a.get_state("TYPE"), state=a.get_state("STATE"))
+    spec2["lists"] = [dict(arity=2, kind="HARMONIC", params=[30.0, 0.97], ids=a.get_list(ha["reaction_bonds"]))]
+    spec2["exclusions"] = a.get_exclusions()
+    c, d, o2 = make_gpu(prec), make_gpu(prec), make_oracle()
+    for e in (c, d, o2):
+        W.apply(spec2, e, thermostat=False, reactions=False)
+    d.set_option("bonds_inline", 0)
+    c.run(0); d.run(0); o2.run(0)
+    fo2 = o2.get_state("FORCE")
+    assert rel_err(c.get_state("FORCE"), fo2) < TOL[prec] and rel_err(d.get_state("FORCE"), fo2) < TOL[prec]
+    assert rel_err(c.get_state("FORCE"), d.get_state("FORCE")) < (1e-12 if prec == 64 else 1e-5)
+    assert c.observe()["epot_list"][0] == pytest.approx(o2.observe()["epot_list"][0], rel=1e-11 if prec == 64 else 1e-5)
+
+
+@pytest.mark.parametrize("narm", [6, 10])
+@pytest.mark.parametrize("prec", [64, 32])
+def test_inline_bonds_with_crowded_centres(make_gpu, make_oracle, prec, narm):
+    """Inline bonds beyond the located-partner path: star molecules whose centre carries SIX bonded (= excluded) partners are
+    recorded by the list build's generic sweep (second slot quad); with TEN -- more than the eight recorded slots -- the
+    centres stay with the work-list kernel while the arms (one bond each) are evaluated inline.  Forces against the oracle
+    and against the all-work-list path, then a short trajectory."""
+    rng = np.random.default_rng(17)
+    k = 9
+    cells = (np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 3) + 0.5) * 3.3
+    arms = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1],
+                     [1, 1, 1], [-1, -1, 1], [1, -1, -1], [-1, 1, -1]], float)[:narm]
+    arms /= np.linalg.norm(arms, axis=1)[:, None]
+    pos = (cells[:, None, :] + np.concatenate([np.zeros((1, 3)), arms])[None]).reshape(-1, 3) + rng.uniform(-0.05, 0.05, (len(cells) * (narm + 1), 3))
+    n = len(pos)
+    ids = np.arange(1, n + 1).reshape(-1, narm + 1)
+    bonds = np.concatenate([np.stack([ids[:, 0], ids[:, a]], 1) for a in range(1, narm + 1)])
+    spec = dict(n=n, box=[k * 3.3] * 3, rc=2.5, skin=0.3, dt=0.002, ids=np.arange(1, n + 1), types=np.zeros(n, np.int32), pos=pos,
+                vel=rng.normal(0, 0.3, (n, 3)), mass=np.ones(n), lj=[(0, 0, 0.5, 0.9, 2.5)], kT=1.0, gamma=0.0, seed=1,
+                lists=[dict(arity=2, kind="HARMONIC", params=[40.0, 1.0], ids=bonds)], exclusions=bonds, rebuild_criterion=0)
+    a, b, o = make_gpu(prec), make_gpu(prec), make_oracle()
+    for e in (a, b, o):
+        W.apply(spec, e, thermostat=False)
+    b.set_option("bonds_inline", 0)
+    a.run(0); b.run(0); o.run(0)
+    fo = o.get_state("FORCE")
+    assert rel_err(a.get_state("FORCE"), fo) < TOL[prec] and rel_err(b.get_state("FORCE"), fo) < TOL[prec]
+    assert rel_err(a.get_state("FORCE"), b.get_state("FORCE")) < (1e-12 if prec == 64 else 1e-5)   # (fp32: 2 K x the 2.4e-7 of a staged coordinate)
+    a.run(60); o.run(60)
+    assert a.timers()["rebuilds"] == o.timers()["rebuilds"] >= 2
+    assert rel_err(a.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 1e-4)
