@@ -159,6 +159,7 @@ struct Ctx {
   int opt_ablate = 0;        // diagnostic only: 1 = pair kernel stops after staging, 2 = skips staging
   int opt_skip_inactive = 1; // force list omits type pairs without a potential
   int opt_bonds_inline = 1;  // harmonic 2-body bonds evaluated by the force kernel from its staged image (when the host can prove it applicable)
+  int opt_tile_split = 0;    // narrow tiles at the end of every tile row (pick_tile_split): 0 off, nb * 10 + w
   int opt_bucket_cap = 0;    // testing: bucket rows of the fused rebuild narrower than 64 (provokes the mid-run overflow recovery)
   int64_t halts_recovered = 0;
   // slab domain decomposition (chem_comm_init)
@@ -178,6 +179,7 @@ struct Ctx {
   virtual void debug_enable(int) {}
   virtual int64_t debug_dump_rebuild(long long*, int64_t) { return 0; }
   virtual int64_t debug_force_list(int, int32_t*, int64_t) { return -1; }
+  virtual void debug_tiles(int32_t* out) = 0;
   virtual void join_async() {}
 };
 
@@ -194,7 +196,9 @@ template <typename R> struct CtxT : Ctx {
   // (fp64 builds use the fp32 list image too -- the force list may be a superset -- and need their own 32-byte-per-slot
   //  image only where the exact int32 rows are built)
   static constexpr size_t kTileLdsBudget = 150 * 1024;   // of 160 KB per CU: the rest is the kernels' static __shared__ (tile tables, scan scratch)
-  size_t tile_lds_need() const { return std::max(std::max(tile_lds_bytes(), pair_lds_bytes()), list_lds_need()); }
+  // reaction scan: the staged image + 4 bytes per slot of role words (k_react_roles)
+  size_t scan_lds_bytes() const { return scan_roles_offset(tile_cap, sizeof(V4)) + (size_t)(tile_cap + 1) * sizeof(unsigned int); }
+  size_t tile_lds_need() const { return std::max(std::max(std::max(tile_lds_bytes(), pair_lds_bytes()), list_lds_need()), scan_lds_bytes()); }
   size_t list_lds_need(bool exact_rows = true) const {
     const size_t lb = list_lds_bytes(tile_cap, kMaxTypes);
     return (sizeof(R) == 4 || exact_rows) ? std::max(tile_lds_bytes(), lb) : lb;
@@ -229,6 +233,7 @@ template <typename R> struct CtxT : Ctx {
   // fused rebuild (single domain, tiles): segment scans + grid barrier state
   DBuf<int> cell_loc, seg_tot, tile_n, tile_loc, tseg_tot, cell_n, bucket; int bcap = 0; DBuf<GridBar> gbar;
   DBuf<int> tile_cnt, tile_off;   // reaction scan on tiles: candidates per tile, their offsets
+  DBuf<unsigned int> scan_role;   // ... and the role bits of every particle slot (k_react_roles)
   DBuf<int4> bwork, bj; int nb_owner = 0; bool bwork_dirty = true;   // bonded work list (see dev_bonded_prep)
   // Inline bonds: all bonded terms are 2-body bonds of ONE harmonic parameter set and the exclusion set is exactly the bond
   // set (chain-growth systems) -> the LDS slots of the excluded partners, which the list build locates anyway, ARE the bonded
@@ -350,6 +355,7 @@ template <typename R> struct CtxT : Ctx {
       box.qsf[d] = (R)q_scale(d); box.qinvf[d] = (R)(1.0 / q_scale(d));
     }
     box.ncell = cells ? nc[0] * nc[1] * nc[2] : 1;
+    box.xs_nb = 1 << 20; box.xs_w = 1;      // (all tiles HX wide until pick_tile_split says otherwise)
     box.zghost = 0; box.z0g = 0; box.nzg = cells ? nc[2] : 1; box.shz_lo = 0; box.shz_hi = 0;
     if (dd_on) {
       if (!cells) throw ChemError(CHEM_EINVAL, "domain decomposition needs at least 3 cells of edge rc+skin per axis");
@@ -383,6 +389,23 @@ template <typename R> struct CtxT : Ctx {
     const double s = edge * (1.0 - 1e-9) - rc;
     return s > skin ? s : 0.0;
   }
+  // Narrow tiles (Box::xs_nb / xs_w, md_kernels.hpp tile_xrange): option tile_split = nb * 10 + w, 0 = off (default).
+  // Built to fill the last round of the force launch (1728 equal one-shot workgroups on 768 resident slots: 2.25 rounds of
+  // work) with shorter jobs, and measured: no gain at any mix -- C5: 7811 steps/s unsplit, 7549 with 10 wide + 6 one-cell
+  // tiles per row, 7721 with 11 + 3; 125k particles: 22980 unsplit, 20134 all one cell wide (profiles/round3_tile_split.txt).
+  // The workgroups of the last round run faster on their emptier CUs than the model assumed; the extra staging is not paid back.
+  void debug_tiles(int32_t* out) override {
+    if (geom_dirty) setup_geometry();
+    const int ntx = use_tiles ? tile_ntx(box.nc[0], box.xs_nb, box.xs_w) : 0;
+    out[0] = ntiles; out[1] = box.nc[0]; out[2] = use_tiles ? tile_nbx(box.nc[0], box.xs_nb) : 0; out[3] = box.xs_w;
+    out[4] = ntx ? ntiles / ntx : 0; out[5] = tile_cap;
+  }
+  void pick_tile_split() {
+    box.xs_nb = 1 << 20; box.xs_w = 1;
+    if (!use_tiles || opt_tile_split <= 0 || HX < 2) return;
+    const int nb = opt_tile_split / 10, w = std::max(1, std::min(opt_tile_split % 10, HX));
+    if (nb * HX < box.nc[0]) { box.xs_nb = nb; box.xs_w = w; }
+  }
   void setup_geometry() {
     skin_list = pick_list_skin();
     setup_geometry_once();
@@ -406,10 +429,14 @@ template <typename R> struct CtxT : Ctx {
       tile_cap = std::max(1024, (need + 255) / 256 * 256);
       // every kernel that stages a tile must fit: the force kernel's image AND the list build's (SoA groups + type masks +
       // slice boundaries: ~22 B per slot against 16), next to the static __shared__ of k_rebuild_fused / k_nlist_tiles
-      if (tile_lds_need() > kTileLdsBudget) use_tiles = false;   // cells too crowded: per-cell kernels
+      if (tile_lds_need() > kTileLdsBudget) {   // cells too crowded: per-cell kernels
+        if (dd_on) throw ChemError(CHEM_ENOSPC, "domain decomposition needs the LDS-staged tiles, and a stencil of this density does not fit the LDS");
+        use_tiles = false;
+      }
       else set_tile_lds_attr();
     }
-    ntiles = use_tiles ? ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY) * (((dd_on ? ncz : box.nc[2]) + HZ - 1) / HZ) : 0;
+    pick_tile_split();
+    ntiles = use_tiles ? tile_ntx(box.nc[0], box.xs_nb, box.xs_w) * ((box.nc[1] + HY - 1) / HY) * (((dd_on ? ncz : box.nc[2]) + HZ - 1) / HZ) : 0;
     alloc_lists();
     setup_fused();
     setup_tile_order();
@@ -459,10 +486,12 @@ template <typename R> struct CtxT : Ctx {
   DBuf<int> tile_pos, tile_ord;
   void setup_tile_order() {
     if (!use_tiles || dd_on || ntiles < 8) { tile_pos.free(); tile_ord.free(); return; }
-    const int ntx = (box.nc[0] + HX - 1) / HX, nty = (box.nc[1] + HY - 1) / HY;
+    const int ntx = tile_ntx(box.nc[0], box.xs_nb, box.xs_w), nty = (box.nc[1] + HY - 1) / HY;
     auto home_cells = [&](int tile) {
       const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
-      return std::min(HX, box.nc[0] - tx * HX) * std::min(HY, box.nc[1] - ty * HY) * std::min(HZ, box.nc[2] - tz * HZ);
+      int cx0, hx;
+      tile_xrange(tx, box.nc[0], box.xs_nb, box.xs_w, cx0, hx);
+      return hx * std::min(HY, box.nc[1] - ty * HY) * std::min(HZ, box.nc[2] - tz * HZ);
     };
     std::vector<int> ord(ntiles), pos(ntiles);
     const int q = ntiles >> 3, r = ntiles & 7;
@@ -508,7 +537,7 @@ template <typename R> struct CtxT : Ctx {
     const int bytes = (int)tile_lds_bytes();
 #define SETA(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nlist_tiles<R, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()));
-    SETA((k_react_scan_tiles<R, 512>));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_react_scan_tiles<R, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes()));
 #define SETB(T, E, M) SETA((k_pair_tiles<R, T, E, 256, M>)); SETA((k_pair_tiles<R, T, E, 512, M>)); SETA((k_pair_tiles<R, T, E, 1024, M>)); \
                       if (T == 1 && !E) SETA((k_pair_tiles<R, 1, false, 512, M, true>))
 #define SETT(E, M) SETB(1, E, M); SETB(2, E, M); SETB(4, E, M); SETB(8, E, M)
@@ -1109,7 +1138,7 @@ template <typename R> struct CtxT : Ctx {
     const bool inline_now = bonds_inline();
     if (use_tiles) {
       // which tiles: all (default), or the interior / boundary subset of a slab (see TileSub)
-      const int ntxy = ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY);
+      const int ntxy = tile_ntx(box.nc[0], box.xs_nb, box.xs_w) * ((box.nc[1] + HY - 1) / HY);
       TileSub ts{0, ntiles, 0};
       int nsub = ntiles;
       if (pair_subset == 1) { ts = TileSub{ntxy, ntiles - 2 * ntxy, 0}; nsub = ntiles - 2 * ntxy; }
@@ -1220,7 +1249,7 @@ template <typename R> struct CtxT : Ctx {
   // position update (posted before the decision is known: it is needed unless we rebuild), and the
   // collective rebuild when the trigger fired.  One host synchronisation per step.
   bool dd_overlap() const {
-    const int ntxy = ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY);
+    const int ntxy = tile_ntx(box.nc[0], box.xs_nb, box.xs_w) * ((box.nc[1] + HY - 1) / HY);
     const bool want_overlap = opt_overlap > 0 || (opt_overlap < 0 && ntiles >= 8192);
     return want_overlap && use_tiles && ntiles > 2 * ntxy && !getenv("CHEM_DD_NOPOLL");
   }
@@ -1251,7 +1280,7 @@ template <typename R> struct CtxT : Ctx {
     // Overlap: the halo exchange runs on the communication stream while the tiles that need no ghost
     // (every tile layer but the lowest and the highest of the slab) already compute their forces.
     // Those launches cannot know the decision yet; if it is "rebuild", everything is recomputed below.
-    const int ntxy = ((box.nc[0] + HX - 1) / HX) * ((box.nc[1] + HY - 1) / HY);
+    const int ntxy = tile_ntx(box.nc[0], box.xs_nb, box.xs_w) * ((box.nc[1] + HY - 1) / HY);
     // Measured with one rank (1M particles, RCCL to self): the cross-stream hand-over costs ~15 us and the
     // boundary launch cannot fill the chip, so the overlap only pays once the interior force kernel is much
     // longer than that -- automatic for slabs of >= 8192 tiles (~4M particles per GPU), option overlap_halo.
@@ -1491,9 +1520,11 @@ template <typename R> struct CtxT : Ctx {
     if (use_tiles) {
       const int region_cap = std::max(1, cand_cap / std::max(ntiles, 1));
       tile_cnt.alloc(ntiles + 1); tile_off.alloc(ntiles + 1);
-      hipLaunchKernelGGL((k_react_scan_tiles<R, 512>), dim3(ntiles), dim3(512), tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, state.p,
+      if (scan_role.n < (size_t)acap()) scan_role.alloc((size_t)acap() + 1024);
+      hipLaunchKernelGGL(k_react_roles<R>, dim3(std::min(cdiv(acap(), 256), 4096)), dim3(256), 0, stream, acap(), nglob, x4.p, tag.p, state.p, rs_dev.p, scan_role.p);
+      hipLaunchKernelGGL((k_react_scan_tiles<R, 512>), dim3(ntiles), dim3(512), scan_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, state.p,
                          res_id.p, mol_id.p, boxd, rs_dev.p, evout.p, region_cap, tile_cnt.p, ctl.p, (R)(0.5 * skin_eff()),
-                         has_excl ? (const int*)excl_start.p : (const int*)nullptr, (const int*)excl_list.p, conn);
+                         has_excl ? (const int*)excl_start.p : (const int*)nullptr, (const int*)excl_list.p, conn, (const unsigned int*)scan_role.p);
       hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, stream, ntiles, tile_cnt.p, tile_off.p, ctl.p);
       hipLaunchKernelGGL(k_cand_gather, dim3(std::min(ntiles, 2048)), dim3(256), 0, stream, ntiles, evout.p, region_cap, tile_cnt.p, tile_off.p, cdst, cand_cap, ctl.p);
     } else {
@@ -1642,13 +1673,15 @@ template <typename R> struct CtxT : Ctx {
     // (pin_ev is not touched again before the next reaction step, which joins the thread first)
     std::thread mirror_thr;
     std::exception_ptr mirror_err;
+    // (measured, round 3: inserting by hash shards on helper threads -- a persistent pool of 1..3 -- made this loop SLOWER,
+    //  1.0-1.7 ms -> 2.0-3.9 ms for 2.4-4.3e4 new bonds on the 2-socket host: the table lives on the caller's NUMA node)
     for (size_t k = 0; k < hev.size(); ++k) {
       const Candidate& e = hev[k];
       const chem_reaction_desc& d = reactions[e.r];
       if (d.is_virtual) break;   // bond-forming events were partitioned to the front
-      if (k + 8 < hev.size() && !reactions[hev[k + 8].r].is_virtual) {   // the de-duplication set is a 10^5-entry hash table: hide its misses
-        int32_t tp[2] = {hev[k + 8].a, hev[k + 8].b};
-        top.lists[reactions[hev[k + 8].r].bond_list].seen.prefetch(tuple_key(tp, 2));
+      if (k + 24 < hev.size() && !reactions[hev[k + 24].r].is_virtual) {   // the de-duplication set is a 10^6-entry hash table: hide its misses
+        int32_t tp[2] = {hev[k + 24].a, hev[k + 24].b};
+        top.lists[reactions[hev[k + 24].r].bond_list].seen.prefetch(tuple_key(tp, 2));
       }
       int32_t t[2] = {e.a, e.b};
       if (top.list_insert(top.lists[d.bond_list], t)) newbonds.emplace_back(e.a, e.b);
@@ -2497,6 +2530,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; CTX.geom_dirty = true; }
   else if (k == "bonds_inline") { CTX.opt_bonds_inline = value != 0; CTX.resort = true; }
   else if (k == "bucket_cap") { CTX.opt_bucket_cap = (int)value; CTX.geom_dirty = true; }
+  else if (k == "tile_split") { CTX.opt_tile_split = (int)value; CTX.geom_dirty = true; CTX.resort = true; }
   else if (k == "list_skin") { CTX.opt_list_skin = value; CTX.geom_dirty = true; CTX.resort = true; }
   else if (k == "debug_stamps") CTX.debug_enable((int)value);
   else if (k == "dd_self") {   // testing: one rank, ghost layers in z exchanged with itself by device copies
@@ -2522,6 +2556,8 @@ int64_t chem_debug_dump(chem_ctx* ctx, long long* out, int64_t cap) { return ctx
 int64_t chem_debug_dump_rebuild(chem_ctx* ctx, long long* out, int64_t cap) { return ctx->c->debug_dump_rebuild(out, cap); }
 // diagnostic / tests: partner tags of the force list of particle `tag`, in list order; -1 without tiles
 // diagnostics / tests (unlisted, like chem_debug_force_list): how many times a run stopped by the device was resumed
+// ... and the tile geometry in use: out[0..5] = tiles, cells along x, wide tiles per row, width of the narrow ones, tile rows, LDS slots per tile
+int64_t chem_debug_tiles(chem_ctx* ctx, int32_t* out) { try { ctx->c->debug_tiles(out); return 0; } catch (...) { return -2; } }
 int64_t chem_debug_halts(chem_ctx* ctx) { return ctx && ctx->c ? ctx->c->halts_recovered : -1; }
 int64_t chem_debug_force_list(chem_ctx* ctx, int32_t tag, int32_t* out, int64_t cap) { try { return ctx->c->debug_force_list(tag, out, cap); } catch (...) { return -2; } }
 

@@ -94,6 +94,9 @@ template <typename R> struct Box {
   // Fixed-point positions (R = float only, see "position codec" below): q = rint((x - L/2) / qs), qs = L / 2^31
   double qs[3], qh[3];     // scale and half box edge (fp64: exact decoding)
   R qsf[3], qinvf[3];      // scale and 1 / scale in R (staging, integrator)
+  // Tile widths along x (see tile_x0): the first xs_nb tiles of a row are HX cells wide, the others xs_w (1 or 2) cells.
+  // xs_nb * HX >= nc[0]: all tiles HX wide.  Narrow tiles are the small change that fills the last round of a force launch.
+  int xs_nb, xs_w;
 };
 
 // ---- position codec ------------------------------------------------------------------------------------------------
@@ -1046,6 +1049,21 @@ constexpr int SX = HX + 2, SY = HY + 2, SZ = HZ + 2;
 constexpr int NROW = SY * SZ;          // x-rows of the stencil
 constexpr int NHSEG = HY * HZ;         // home x-runs (contiguous in memory)
 
+// Tiles along x: xs_nb tiles of HX cells, then tiles of xs_w cells (Box::xs_nb / xs_w).  A force launch of one-shot
+// workgroups ends with a partly filled last round (1728 equal tiles on 768 resident slots: 2.25 rounds take the time of 3);
+// a share of narrow tiles -- shorter jobs, scheduled last by the largest-first order -- fills it.  Splitting along x (the
+// fastest tile index) gives every XCD's contiguous tile range the same mix.
+__host__ __device__ inline int tile_nbx(int nx, int xs_nb) { return xs_nb * HX >= nx ? (nx + HX - 1) / HX : xs_nb; }      // wide tiles in a row (the last may be cut)
+__host__ __device__ inline int tile_ntx(int nx, int xs_nb, int xs_w) {
+  const int nb = tile_nbx(nx, xs_nb);
+  return nb * HX >= nx ? nb : nb + (nx - nb * HX + xs_w - 1) / xs_w;
+}
+__host__ __device__ inline void tile_xrange(int tx, int nx, int xs_nb, int xs_w, int& cx0, int& hx) {
+  const int nb = tile_nbx(nx, xs_nb);
+  if (tx < nb) { cx0 = tx * HX; hx = HX < nx - cx0 ? HX : nx - cx0; }
+  else { cx0 = nb * HX + (tx - nb) * xs_w; hx = xs_w < nx - cx0 ? xs_w : nx - cx0; }
+}
+
 // positions live in dynamic LDS (capacity chosen at run time from the cell occupancy):
 // sx[0..cap], slot `total` is a far-away dummy used as row padding
 template <typename R> struct TileLDS {
@@ -1081,12 +1099,14 @@ template <typename R>
 __device__ __forceinline__ void tile_tables(TileLDS<R>& T, const int CAP, int tile, const int* __restrict__ cell_start,
                                             const Box<R>& box, DevCtl* ctl, const int* __restrict__ cell_sub = nullptr) {
   const int nx = box.nc[0], ny = box.nc[1], nz = box.nc[2];
-  const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
+  const int ntx = tile_ntx(nx, box.xs_nb, box.xs_w), nty = (ny + HY - 1) / HY;
   const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
   // z-ghost mode: layers 1..nz-2 are own, the stencil reaches into the ghost layers 0 and nz-1
   const int zg = box.zghost;
-  const int cx0 = tx * HX, cy0 = ty * HY, cz0 = tz * HZ + zg;
-  const int hx = min(HX, nx - cx0), hy = min(HY, ny - cy0), hz = min(HZ, nz - zg - cz0);
+  int cx0, hx;
+  tile_xrange(tx, nx, box.xs_nb, box.xs_w, cx0, hx);
+  const int cy0 = ty * HY, cz0 = tz * HZ + zg;
+  const int hy = min(HY, ny - cy0), hz = min(HZ, nz - zg - cz0);
   const int t = threadIdx.x;
   if (t < NROW * SX) {
     const int r = t / SX, k = t % SX, ry = r % SY, rz = r / SY;
@@ -1395,9 +1415,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-__device__ __forceinline__ int ntiles_of(const int nc[3]) {
-  return ((nc[0] + HX - 1) / HX) * ((nc[1] + HY - 1) / HY) * ((nc[2] + HZ - 1) / HZ);
-}
 
 // ---- list build on tiles.  Two products from one sweep:
 //   nl16/nnh  : 16-bit LDS slots of the pairs that carry a non-bonded potential (type-pair mask
@@ -2567,11 +2584,13 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
     dev_sort_gather_bucket<R>(a.ncell, a.cell_cnt, s_off, a.seg_shift, a.bucket, a.bcap, a.cell_start, a.x4, a.v4, a.tag, a.img4,
                               a.x4o, a.v4o, a.tago, a.img4o, a.rtag, a.box, a.cell_sub);
     const int nx = a.box.nc[0], ny = a.box.nc[1], nz = a.box.nc[2];
-    const int ntx = (nx + HX - 1) / HX, nty = (ny + HY - 1) / HY;
+    const int ntx = tile_ntx(nx, a.box.xs_nb, a.box.xs_w), nty = (ny + HY - 1) / HY;
     for (int tile = b * BS + t; tile < a.ntiles; tile += NB * BS) {
       const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
-      const int cx0 = tx * HX, cy0 = ty * HY, cz0 = tz * HZ;
-      const int hx = min(HX, nx - cx0), hy = min(HY, ny - cy0), hz = min(HZ, nz - cz0);
+      int cx0, hx;
+      tile_xrange(tx, nx, a.box.xs_nb, a.box.xs_w, cx0, hx);
+      const int cy0 = ty * HY, cz0 = tz * HZ;
+      const int hy = min(HY, ny - cy0), hz = min(HZ, nz - cz0);
       int nh = 0;
       for (int hzi = 0; hzi < hz; ++hzi) for (int hyi = 0; hyi < hy; ++hyi) {
         const int c0 = ((cz0 + hzi) * ny + (cy0 + hyi)) * nx + cx0;
@@ -2918,6 +2937,54 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
 }
 
 // ---- reaction scan on the staged tiles, WITHOUT rebuilding anything.
+// Role words of the reaction scan on tiles: for every particle slot (position order) one bit per reaction and role -- bit q:
+// "type and state fit role 1 of (active) reaction q", bit 16 + q: role 2 (CHEM_MAX_REACTIONS = 16).  One streaming pass in
+// front of the scan (tag -> state is the only gather); the scan stages the words beside the positions (4 bytes per slot), so
+// that the role compatibility of a candidate pair is decided in LDS and only the pairs that can react reach the dependent
+// global loads (tags, exclusion row, labels, exact fp64 distance).
+template <typename R>
+__global__ __launch_bounds__(256) void k_react_roles(int nslot, int ntag, const Vec4<R>* __restrict__ x4, const int* __restrict__ tag,
+                                                     const int* __restrict__ state, const ReactSet* __restrict__ rs_g, unsigned int* __restrict__ role) {
+  __shared__ ReactSet rs;
+  {
+    const int* src = reinterpret_cast<const int*>(rs_g);
+    int* dst = reinterpret_cast<int*>(&rs);
+    for (int k = threadIdx.x; k < (int)(sizeof(ReactSet) / 4); k += 256) dst[k] = src[k];
+  }
+  __syncthreads();
+  for (int g = blockIdx.x * 256 + threadIdx.x; g < nslot; g += gridDim.x * 256) {
+    const int tg = tag[g];
+    unsigned int bits = 0;
+    if (tg >= 0 && tg < ntag) {
+      const int t = (int)x4[g].w, st = state[tg];
+      for (int q = 0; q < rs.n; ++q) {
+        const ReactionDev& R_ = rs.r[q];
+        if (!R_.active) continue;
+        if (t == R_.type_1 && st >= R_.min1 && st < R_.max1) bits |= 1u << q;
+        if (t == R_.type_2 && st >= R_.min2 && st < R_.max2) bits |= 1u << (16 + q);
+      }
+    }
+    role[g] = bits;
+  }
+}
+// stages role[g] of every stencil slot (same addressing as tile_fill's register-lean form)
+template <typename R, int BS>
+__device__ __forceinline__ void tile_fill_roles(const TileLDS<R>& T, unsigned int* const sr, const int CAP, const unsigned int* __restrict__ role) {
+  constexpr int NW = BS / 64;
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int r = w; r < NROW; r += NW) {
+    const int len = T.celloff[r][SX], o0 = T.rowoff[r];
+    for (int e = l; e < len; e += 64) {
+      int k = 0;
+#pragma unroll
+      for (int q = 1; q < SX; ++q) k += (e >= T.celloff[r][q]) ? 1 : 0;
+      const int g = T.cellg[r][k] + (e - T.celloff[r][k]);
+      if (o0 + e < CAP) sr[o0 + e] = role[g];
+    }
+  }
+}
+__host__ __device__ constexpr size_t scan_roles_offset(int CAP, size_t slot_bytes) { return ((size_t)(CAP + 5) * slot_bytes + 15) / 16 * 16; }
+
 // The int32-list scan above needs a fresh list, i.e. a forced rebuild at the reaction step -- and a
 // rebuild re-sorts the particles but not their forces, which the next half-kick still needs (the
 // reaction sits between the force evaluation of step s and the first kick of step s+1).  This
@@ -2927,6 +2994,8 @@ __global__ __launch_bounds__(256) void k_react_scan(int i0, int n, const Vec4<R>
 // into LDS.  Per home particle: fp32 pre-test of the stencil candidates against the largest
 // reaction radius, then for the few survivors (tag order, states, labels) the fp64 distance from
 // the global arrays exactly as k_react_scan computes it, the reaction filters and the Philox draw.
+// Round 3: tag and role bits are staged beside the positions (k_react_roles), so a home particle without a role costs
+// nothing and a candidate reaches the global loads only if tag order and roles allow a reaction.
 // Output: every tile appends to its own fixed region of `region` through an LDS counter (no
 // contended global atomic); k_cand_offsets / k_cand_gather compact the regions afterwards.
 template <typename R, int BS>
@@ -2935,11 +3004,13 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
                                                             const int* __restrict__ res_id, const int* __restrict__ mol_id, BoxD box,
                                                             const ReactSet* __restrict__ rs_g, Candidate* __restrict__ region, int region_cap,
                                                             int* __restrict__ tile_count, DevCtl* ctl, R slack,
-                                                            const int* __restrict__ excl_start, const int* __restrict__ excl_list, ConnTable conn) {
+                                                            const int* __restrict__ excl_start, const int* __restrict__ excl_list, ConnTable conn,
+                                                            const unsigned int* __restrict__ role) {
   __shared__ TileLDS<R> T;
   __shared__ ReactSet rs;
   __shared__ int s_cnt;
   CHEM_DYN_LDS(R);
+  unsigned int* const sr = reinterpret_cast<unsigned int*>(chem_dyn_lds + scan_roles_offset(CAP, sizeof(Vec4<R>)));   // role words behind the image
   {
     const int* src = reinterpret_cast<const int*>(rs_g);
     int* dst = reinterpret_cast<int*>(&rs);
@@ -2956,8 +3027,11 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
+    tile_fill_roles<R, BS>(T, sr, CAP, role);
     __syncthreads();
     const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4];
+    if (threadIdx.x == 0 && total < CAP) sr[total] = 0u;      // (the far-away dummy slot: no role)
+    __syncthreads();
     Candidate* out = region + (size_t)tile * region_cap;
     for (int q = threadIdx.x; q < nhome; q += BS) {
       int sgi = 0;
@@ -2971,15 +3045,12 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
       int lx = 0;
       for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
       const int sself = T.rowoff[hr] + eh;
+      const unsigned int rwi = sr[sself];
+      if (!rwi) continue;                                     // no role in any active reaction
       const Vec4<R> xi = sx[sself];
-      const int ti = real_as_idx(xi.w) & 15, tgi = tag[p];
-      const int si = state[tgi], ri = res_id[tgi], mi = mol_id[tgi];
-      bool any = false;
-      for (int k = 0; k < rs.n; ++k) {
-        const ReactionDev& R_ = rs.r[k];
-        if (R_.active) any |= (ti == R_.type_1 && si >= R_.min1 && si < R_.max1) || (ti == R_.type_2 && si >= R_.min2 && si < R_.max2);
-      }
-      if (!any) continue;
+      const int tgi = tag[p];
+      const unsigned int ri1 = rwi & 0xffffu, ri2 = rwi >> 16;
+      const int ri = res_id[tgi], mi = mol_id[tgi];
       const Vec4<R> xgi = x4[p];
       // x-window of every stencil row, as in the list build (dev_nlist_tile) but for the largest reaction radius and
       // with the tables of the LAST rebuild: a candidate sits within `slack` (= skin/2) of where it was binned, so the
@@ -3023,7 +3094,10 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
           const Vec4<R> xj = xq[u];
           const R dx = xi.x - xj.x, dy_ = xi.y - xj.y, dz_ = xi.z - xj.z;
           if (dx * dx + dy_ * dy_ + dz_ * dz_ > maxcut2 || sl == sself || sl >= b) continue;
-          const int jw = real_as_idx(xj.w), j = jw >> 5, tj = jw & 15;
+          const unsigned int rwj = sr[sl];
+          const unsigned int fwdm = ri1 & (rwj >> 16), revm = ri2 & (rwj & 0xffffu);   // bit q: reaction q with (i, j) as roles (1, 2) / (2, 1)
+          if (!(fwdm | revm)) continue;
+          const int j = real_as_idx(xj.w) >> 5;
           const int tgj = tag[j];
           if (!(tgi < tgj)) continue;          // every pair once, from its lower tag (on the rank that owns it)
           if (excl_start) {                    // candidates are Verlet-list pairs: an excluded (e.g. bonded) pair never reacts
@@ -3031,14 +3105,12 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
             for (int e = excl_start[tgi]; e < excl_start[tgi + 1]; ++e) ex |= excl_list[e] == tgj;
             if (ex) continue;
           }
-          const int sj = state[tgj], rj = res_id[tgj], mj = mol_id[tgj];
+          const int rj = res_id[tgj], mj = mol_id[tgj];
           const D3 d = minimgD(box, posD<R>(xgi, box) - posD<R>(x4[j], box));
           const double d2 = dist2_unfused(d);
           for (int k = 0; k < rs.n; ++k) {
             const ReactionDev& R_ = rs.r[k];
-            if (!R_.active) continue;
-            const bool fwd = ti == R_.type_1 && si >= R_.min1 && si < R_.max1 && tj == R_.type_2 && sj >= R_.min2 && sj < R_.max2;
-            const bool rev = tj == R_.type_1 && sj >= R_.min1 && sj < R_.max1 && ti == R_.type_2 && si >= R_.min2 && si < R_.max2;
+            const bool fwd = (fwdm >> k) & 1u, rev = (revm >> k) & 1u;      // (bits exist for active reactions only)
             if (!(fwd || rev)) continue;
             if (!R_.intraresidual && ri == rj) continue;
             if (!R_.intramolecular && mi == mj) continue;

@@ -426,3 +426,43 @@ def test_inline_bonds_with_crowded_centres(make_gpu, make_oracle, prec, narm):
     a.run(60); o.run(60)
     assert a.timers()["rebuilds"] == o.timers()["rebuilds"] >= 2
     assert rel_err(a.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 1e-4)
+
+
+def _tiles_in_use(g):
+    import ctypes
+    out = (ctypes.c_int32 * 6)()
+    g.api.lib.chem_debug_tiles.restype = ctypes.c_int64
+    assert g.api.lib.chem_debug_tiles(ctypes.c_void_p(g.ctx), out) == 0
+    return list(out)
+
+
+@pytest.mark.parametrize("split", [11, 2, 21])
+@pytest.mark.parametrize("prec", [64, 32])
+def test_narrow_tiles_change_nothing(make_gpu, make_oracle, prec, split):
+    """Option tile_split = nb * 10 + w: the first nb tiles of every tile row are three cells wide, the others w cells (the
+    small change that fills the last round of a force launch).  Same lists, forces, events and trajectory as the oracle --
+    the tiling is invisible -- including bonds evaluated inline and a frozen-position reaction step."""
+    spec = W.reactive_melt(n=8788, seed=61, interval=20)       # 7 cells per axis
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e9
+    g, o, h = both(make_gpu, make_oracle, spec, prec)
+    g.set_option("tile_split", split)
+    g.run(0); o.run(0)
+    ntiles, nx, nwide, w, rows, cap = _tiles_in_use(g)
+    assert nx == 7 and nwide == split // 10 and w == split % 10
+    assert ntiles == rows * (nwide + -(-(nx - 3 * nwide) // w))
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < TOL[prec]
+    og, oo = g.observe(), o.observe()
+    assert og["epot_lj"] == pytest.approx(oo["epot_lj"], rel=1e-11 if prec == 64 else 2e-6)
+    for _ in range(3):
+        g.run(20); o.run(20)
+    assert g.timers()["rebuilds"] == o.timers()["rebuilds"]
+    assert len(o.get_events()) > 1000
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < (TOL[prec] if prec == 64 else 5e-3)   # (fp32: trajectories have drifted by rounding)
+    if prec == 64:
+        assert [e[:4] for e in sorted_events(g.get_events())] == [e[:4] for e in sorted_events(o.get_events())]
+        assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+        assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+        assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())      # (last: the int32 rows come from a forced rebuild)
+    else:
+        assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-4
