@@ -252,7 +252,7 @@ template <typename R> struct CtxT : Ctx {
   }
   double inline_K = 0, inline_r0 = 0;
   bool bonds_inline() {
-    if (!opt_bonds_inline || !use_fused || dd_on || nbent <= 0 || !harmonic_only || !bonds_excluded) return false;
+    if (!opt_bonds_inline || !(use_fused || (dd_on && use_tiles)) || nbent <= 0 || !harmonic_only || !bonds_excluded) return false;
     // the exclusion set must BE the bond set (bonds are a subset: bonds_excluded; both are duplicate-free): equal counts
     size_t nb2 = 0;
     for (const auto& l : top.lists) if (l.arity == 2) nb2 += (size_t)l.size();
@@ -295,7 +295,7 @@ template <typename R> struct CtxT : Ctx {
   DBuf<double> redbuf;                 // small device buffer for cross-rank reductions
   DBuf<Candidate> cand_loc; DBuf<int> cnt_all;   // reaction candidates before the all-gather
   int acap() const { return dd_on ? cap : n; }
-  int64_t dd_rebuilds = 0;
+  int64_t dd_rebuilds = 0, dd_direct_rebuilds = 0;   // slab rebuilds: all of them / those the host called for itself (rebuild_now)
   int* hflag = nullptr; int* hflag_dev = nullptr; int hticket = 0;   // pinned decision word + ticket
   DBuf<double> dd_vals;
   int S = 0;
@@ -377,13 +377,14 @@ template <typename R> struct CtxT : Ctx {
   // workload's skin would give, i.e. ~0.2 sigma more skin at rc + skin = 2.8 -- the lists live ~60 % longer for ~20 % more
   // entries -- and always the whole cell edge (the slack between L / floor(L / rl) and rl is free skin).
   double pick_list_skin() const {
-    if (opt_list_skin == 0.0 || opt_criterion != 0 || dd_on || !opt_fused || !opt_tiles) return 0.0;
+    if (opt_list_skin == 0.0 || opt_criterion != 0 || !opt_tiles || (!dd_on && !opt_fused)) return 0.0;
     const double rl = rc + skin;
     double edge = 1e300;
     for (int d = 0; d < 3; ++d) {
       int nc = (int)std::floor(L[d] / (opt_list_skin > 0 ? rc + opt_list_skin : rl));
-      if (opt_list_skin < 0) { if (n < 100000) return 0.0; nc -= 2; }
+      if (opt_list_skin < 0) { if ((dd_on ? nglob : n) < 100000) return 0.0; nc -= 2; }
       if (nc < 5) return 0.0;
+      if (dd_on && d == 2 && nc / P < 2) return 0.0;      // (a slab needs two cell layers)
       edge = std::min(edge, L[d] / nc);
     }
     const double s = edge * (1.0 - 1e-9) - rc;
@@ -409,7 +410,7 @@ template <typename R> struct CtxT : Ctx {
   void setup_geometry() {
     skin_list = pick_list_skin();
     setup_geometry_once();
-    if (skin_list > 0 && !use_fused) { skin_list = 0.0; setup_geometry_once(); }   // the wider skin only pays on the fused tile path
+    if (skin_list > 0 && !use_fused && !dd_on) { skin_list = 0.0; setup_geometry_once(); }   // the wider skin only pays on the fused tile path
   }
   void setup_geometry_once() {
     setup_box();
@@ -561,6 +562,7 @@ template <typename R> struct CtxT : Ctx {
     n = nglob; G = 0; nglo = ngup = 0; cap = nglob;
     std::vector<V4> hx, hv; std::vector<int> ht; std::vector<int4> hi;
     if (dd_on) {
+      skin_list = pick_list_skin();   // (the slab bounds below must be those of the geometry set up afterwards)
       setup_box();   // slab bounds (z0, ncz, nzg)
       // capacities: ghost layers are one cell layer each; reals fluctuate with the slab occupancy
       const double per_layer = (double)nglob / nzg;
@@ -902,12 +904,17 @@ template <typename R> struct CtxT : Ctx {
   }
   void launch_list_chain() {
     DevCtl* c = ctl.p;
-    const R rl2 = (R)((rc + skin) * (rc + skin));
+    const R rl2 = (R)((rc + skin_eff()) * (rc + skin_eff())), rl2_rows = (R)((rc + skin) * (rc + skin));   // (they differ on the tile path only)
     if (use_tiles) {
+      uint4* bs = nullptr;      // inline bonds (decomposed path: the standalone list kernel records the partner slots)
+      if (dd_on && bonds_inline()) {
+        if (bslots.n < 2 * (size_t)acap()) bslots.alloc(2 * (size_t)acap() + 1024);
+        bs = bslots.p;
+      }
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c, (const int*)cell_sub.p);
       hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
       hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), list_lds_need(want32), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
-                         excl_start.p, excl_list.p, has_excl, act, ntypes, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c);
+                         excl_start.p, excl_list.p, has_excl, act, ntypes, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c, rl2_rows, bs);
     } else if (box.nc[0] > 0)
       hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
                          excl_start.p, excl_list.p, has_excl, nlist.p, nn.p, S, c);
@@ -929,7 +936,7 @@ template <typename R> struct CtxT : Ctx {
 
   void decide_and_rebuild() {
     if (use_fused) { tbeg(1); launch_rebuild_fused(); tend(); return; }
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, kIntPerBlock), 0.5 * skin, opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(n, kIntPerBlock), 0.5 * skin_eff(), opt_criterion, 3, (const double*)nullptr, 0, (volatile int*)nullptr, 0, 0.5 * skin);
     launch_rebuild_chain();
   }
 
@@ -1062,7 +1069,12 @@ template <typename R> struct CtxT : Ctx {
   void rebuild_now() {
     const double t0 = now_s();
     for (int attempt = 0; attempt < 6; ++attempt) {
-      if (dd_on) { set_ctl_field(&DevCtl::force_rebuild, 0); set_ctl_field(&DevCtl::acc_maxdist, 0.0); HIPCHK(hipMemsetAsync(ctl.p->acc_pp, 0, 2 * sizeof(double), stream)); rebuild_dd(); }
+      if (dd_on) {      // (a slab rebuild the host calls for, not one of the device's decisions: counted on the host)
+        set_ctl_field(&DevCtl::force_rebuild, 0); set_ctl_field(&DevCtl::acc_maxdist, 0.0); set_ctl_field(&DevCtl::acc_ref, 0.0);
+        HIPCHK(hipMemsetAsync(ctl.p->acc_pp, 0, 2 * sizeof(double), stream));
+        if (attempt == 0) ++dd_direct_rebuilds;
+        rebuild_dd();
+      }
       else { set_ctl_field(&DevCtl::force_rebuild, 1); decide_and_rebuild(); }
       DevCtl h = read_ctl();
       if (dd_on) agree_flags(h);
@@ -1231,7 +1243,7 @@ template <typename R> struct CtxT : Ctx {
               (g.stamp[3] - g.stamp[2]) * 0.01, (g.stamp[4] - g.stamp[3]) * 0.01, (g.stamp[5] - g.stamp[4]) * 0.01, (g.stamp[6] - g.stamp[5]) * 0.01);
     }
     if (dd_on) agree_flags(h);
-    tm.rebuilds = dd_on ? dd_rebuilds : h.ref_rebuilds;   // the reference rule's count (== rebuild_count unless a wider list skin is in use)
+    tm.rebuilds = h.ref_rebuilds + (dd_on ? dd_direct_rebuilds : 0);   // the reference rule's count (== the list builds unless a wider list skin is in use)
     tm.list_rebuilds = dd_on ? dd_rebuilds : h.rebuild_count;
     if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
     if (h.bonded_missing) throw ChemError(CHEM_ESTATE, "domain decomposition: a bonded partner is farther than the ghost layer (rc+skin)");
@@ -1258,12 +1270,12 @@ template <typename R> struct CtxT : Ctx {
   void dd_step_sync() {
     ensure_hflag();
     if (dd_merged()) {
-      hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), kIntPerBlock), 0.5 * skin, opt_criterion, 1,
-                         (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+      hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), kIntPerBlock), 0.5 * skin_eff(), opt_criterion, 1,
+                         (const double*)nullptr, 0, (volatile int*)nullptr, 0, 0.5 * skin);
       tr->exchange_with_scalar(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
                                x4.p + G - nglo, nglo * sizeof(V4), lower, upper, &ctl.p->step_m2, dd_vals.p, stream);
       const int ticket = ++hticket;
-      pair_da = DecideArgs{dd_vals.p, P, (volatile int*)hflag_dev, ticket, dd_par, opt_criterion};
+      pair_da = DecideArgs{dd_vals.p, P, (volatile int*)hflag_dev, ticket, dd_par, opt_criterion, 0.5 * skin};
       dd_par ^= 1;
       compute_forces(true, 0);     // (guard 2: decision in the prologue of the force kernel)
       pair_da = DecideArgs{};
@@ -1275,8 +1287,8 @@ template <typename R> struct CtxT : Ctx {
     // local fold -> ctl->step_m2; its all-to-all rides in the halo exchange group; decision from the
     // P gathered values, mirrored into pinned host memory so that the host learns it by polling one
     // word (no memcpy, no stream synchronisation call)
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), kIntPerBlock), 0.5 * skin, opt_criterion, 1,
-                       (const double*)nullptr, 0, (volatile int*)nullptr, 0);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), kIntPerBlock), 0.5 * skin_eff(), opt_criterion, 1,
+                       (const double*)nullptr, 0, (volatile int*)nullptr, 0, 0.5 * skin);
     // Overlap: the halo exchange runs on the communication stream while the tiles that need no ghost
     // (every tile layer but the lowest and the highest of the slab) already compute their forces.
     // Those launches cannot know the decision yet; if it is "rebuild", everything is recomputed below.
@@ -1304,8 +1316,8 @@ template <typename R> struct CtxT : Ctx {
       HIPCHK(hipStreamWaitEvent(stream, ev_halo, 0));
     }
     const int ticket = ++hticket;
-    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, 0, 0.5 * skin, opt_criterion, 2,
-                       dd_vals.p, P, (volatile int*)hflag_dev, ticket);
+    hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, 0, 0.5 * skin_eff(), opt_criterion, 2,
+                       dd_vals.p, P, (volatile int*)hflag_dev, ticket, 0.5 * skin);
     // The force kernels are enqueued BEFORE the host looks at the decision: they leave at once when a
     // rebuild is pending (then the host rebuilds and launches them again), otherwise the device never
     // waits for the host's poll + launch latency.

@@ -21,6 +21,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -193,7 +194,8 @@ struct LocalHub {
     std::unique_lock<std::mutex> lk(mu);
     const long long g = gen;
     if (++arrived == P) { arrived = 0; ++gen; cv.notify_all(); }
-    else cv.wait(lk, [&] { return gen != g; });
+    else if (!cv.wait_for(lk, std::chrono::seconds(90), [&] { return gen != g; }))      // (a rank that failed never arrives: an error here, not a hang)
+      throw ChemError(CHEM_ECOMM, "local transport: a rank did not reach the rendezvous within 90 s (did it fail?)");
   }
 };
 

@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
 // phase 2: decide from ctl->step_m2.
 template <typename R>
 __global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned long long* __restrict__ blockmax, int nblk, double half_skin, int criterion, int phase,
-                                                         const double* __restrict__ gathered, int ngathered, volatile int* __restrict__ host_flag, int ticket) {
+                                                         const double* __restrict__ gathered, int ngathered, volatile int* __restrict__ host_flag, int ticket,
+                                                         double half_skin_ref) {      // (half_skin: the skin the lists were built for; _ref: the workload's, for the reported count)
   unsigned long long m = 0;
   if (phase & 1) {
     for (int k = threadIdx.x; k < nblk; k += 1024) { unsigned long long b = blockmax[k]; blockmax[k] = 0ull; m = b > m ? b : m; }
@@ -314,10 +315,13 @@ __global__ __launch_bounds__(1024) void k_rebuild_decide(DevCtl* ctl, unsigned l
     } else if (gathered) { m2 = gathered[0]; for (int q = 1; q < ngathered; ++q) m2 = gathered[q] > m2 ? gathered[q] : m2; }
     else m2 = ctl->step_m2;
     if (phase & 2) {
+      const int forced = ctl->force_rebuild;
       double acc = criterion ? sqrt(m2) : ctl->acc_maxdist + sqrt(m2);
-      const int need = (acc > half_skin) || ctl->force_rebuild;
-      if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; ctl->ref_rebuilds++; }
-      ctl->acc_maxdist = acc; ctl->acc_ref = acc;
+      double accr = criterion ? sqrt(m2) : ctl->acc_ref + sqrt(m2);
+      const int need = (acc > half_skin) || forced;
+      if (need) { acc = 0.0; ctl->force_rebuild = 0; ctl->rebuild_count++; }
+      if ((accr > half_skin_ref) || forced) { accr = 0.0; ctl->ref_rebuilds++; }      // the reference rule on the workload's skin
+      ctl->acc_maxdist = acc; ctl->acc_ref = accr;
       ctl->need_rebuild = need;
       if (host_flag) {   // pinned, host-visible: [0] decision, [1] ticket (written last); the host spins on the ticket
         host_flag[0] = need;
@@ -1808,7 +1812,8 @@ __global__ __launch_bounds__(BS, 4) void k_nlist_tiles(int ntiles, int CAP, cons
                                                     const TileLDS<R>* __restrict__ desc, R rl2,
                                                     const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
                                                     ActMask act, int ntypes, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
-                                                    int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl) {
+                                                    int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl, R rl2_rows, uint4* __restrict__ bslots) {
+  // (rl2: the radius the 16-bit force list is built for, rc + list skin; rl2_rows: the int32 Verlet rows', rc + skin)
   if (!ctl->need_rebuild) return;
   __shared__ TileLDS<R> T;
   CHEM_DYN_LDS(R);
@@ -1824,11 +1829,11 @@ __global__ __launch_bounds__(BS, 4) void k_nlist_tiles(int ntiles, int CAP, cons
       list_stage_f32<R, BS>(T, chem_dyn_lds, L, CAP, x4, act, ntypes);
       __syncthreads();
       dev_nlist_tile_f32<R, BS>(T, chem_dyn_lds, L, tag, (float)rl2, excl_start, excl_list, has_excl, nl16, S16, nnh, nlist, S, nn, ctl,
-                                (const Box<R>*)nullptr, nullptr, x4);
+                                (const Box<R>*)nullptr, nullptr, x4, 0, (float)rl2_rows, bslots);      // (bslots: inline bonds, see dev_nlist_tile_f32)
     } else {
       tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
       __syncthreads();
-      dev_nlist_tile<R, BS>(T, sx, tag, rl2, excl_start, excl_list, has_excl, act, nl16, S16, nnh, nlist, S, nn, ctl);
+      dev_nlist_tile<R, BS>(T, sx, tag, rl2, excl_start, excl_list, has_excl, act, nl16, S16, nnh, nlist, S, nn, ctl, nullptr, nullptr, nullptr, rl2_rows);
     }
   }
 }
@@ -1903,7 +1908,7 @@ struct TileSub { int base1, n1, base2; };
 // gathered step maxima (same inputs, same arithmetic: same result), workgroup 0 publishes it -- control block, pinned
 // host words the host polls -- and all leave at once when a rebuild is due: no one-block decision launch between the
 // halo exchange and the forces.  The accumulated distance is double-buffered by step parity (read [par], written [par^1]).
-struct DecideArgs { const double* gathered; int n; volatile int* host_flag; int ticket, par, criterion; };
+struct DecideArgs { const double* gathered; int n; volatile int* host_flag; int ticket, par, criterion; double half_skin_ref; };
 
 // (fp64: the 32-byte-per-slot image allows one or two workgroups per CU anyway -- 128 registers instead of 80 and spills)
 // DIAG = true: diagnostic instantiation with per-block phase stamps (`dbg`) and early exits (`ablate`: 1 stop after
@@ -1930,9 +1935,16 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
     double m2 = da.gathered[0];
     for (int q = 1; q < da.n; ++q) m2 = da.gathered[q] > m2 ? da.gathered[q] : m2;
     const double acc = da.criterion ? sqrt(m2) : ctl->acc_pp[da.par] + sqrt(m2);
-    const int need = (acc > half_skin) || ctl->force_rebuild;
+    const int forced = ctl->force_rebuild;
+    const int need = (acc > half_skin) || forced;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       ctl->step_m2 = m2; ctl->acc_pp[da.par ^ 1] = need ? 0.0 : acc; ctl->acc_maxdist = need ? 0.0 : acc;
+      {      // the reference rule on the workload's skin (reported rebuild count; these two words are this thread's alone)
+        const double accr = da.criterion ? sqrt(m2) : ctl->acc_ref + sqrt(m2);
+        const bool rn = (accr > da.half_skin_ref) || forced;
+        ctl->acc_ref = rn ? 0.0 : accr;
+        if (rn) ctl->ref_rebuilds++;
+      }
       // (force_rebuild is NOT cleared here: workgroups that start later must read the same value -- the host clears it,
       //  stream-ordered, at the top of the slab rebuild this decision triggers)
       if (need) ctl->rebuild_count++;

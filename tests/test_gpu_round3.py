@@ -466,3 +466,47 @@ def test_narrow_tiles_change_nothing(make_gpu, make_oracle, prec, split):
         assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())      # (last: the int32 rows come from a forced rebuild)
     else:
         assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-4
+
+
+@pytest.mark.parametrize("prec", [64, 32])
+def test_decomposed_path_with_list_skin_and_inline_bonds(make_gpu, make_oracle, prec):
+    """The slab path (one rank, its own z-neighbour: dd_self) with this round's additions: lists on the internal list skin
+    (reported rebuild count = the reference rule's), harmonic reaction bonds evaluated inline by the force kernel.  Events,
+    bonds, rebuild count and trajectory against the oracle, then the forces of the final configuration against the oracle
+    and against the same engine with both switched off."""
+    spec = W.reactive_melt(n=8788, seed=91, interval=10)
+    spec["rebuild_criterion"] = 0
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e9
+    g, o, s1 = make_gpu(prec), make_oracle(), make_gpu(prec)
+    g.set_option("dd_self", 1)
+    g.set_option("list_skin", 0.55)
+    h = W.apply(spec, g); W.apply(spec, o); W.apply(spec, s1)
+    for _ in range(4):
+        g.run(10); o.run(10); s1.run(10)
+    tg, to, ts = g.timers(), o.timers(), s1.timers()
+    # (the first reaction step changes types without making a bond: the HIP engines refresh their type-filtered force list
+    #  there, the oracle's list holds all pairs and stays -- one forced build more than the oracle on either HIP path)
+    assert tg["rebuilds"] == ts["rebuilds"] and to["rebuilds"] <= tg["rebuilds"] <= to["rebuilds"] + 1
+    assert tg["list_rebuilds"] < tg["rebuilds"]
+    assert len(o.get_list(h["reaction_bonds"])) > 300
+    if prec == 64:
+        assert [e[:4] for e in sorted_events(g.get_events())] == [e[:4] for e in sorted_events(o.get_events())]
+        assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+        assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+    else:
+        assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-4
+    spec2 = dict(spec, pos=g.get_state("POS"), vel=g.get_state("VEL"), types=g.get_state("TYPE"), state=g.get_state("STATE"))
+    spec2["lists"] = [dict(arity=2, kind="HARMONIC", params=[30.0, 0.97], ids=g.get_list(h["reaction_bonds"]))]
+    spec2["exclusions"] = g.get_exclusions()
+    c, d, o2 = make_gpu(prec), make_gpu(prec), make_oracle()
+    for e in (c, d):
+        e.set_option("dd_self", 1)
+    d.set_option("bonds_inline", 0); d.set_option("list_skin", 0)
+    c.set_option("list_skin", 0.55)
+    for e in (c, d, o2):
+        W.apply(spec2, e, thermostat=False, reactions=False)
+    c.run(0); d.run(0); o2.run(0)
+    fo2 = o2.get_state("FORCE")
+    assert rel_err(c.get_state("FORCE"), fo2) < TOL[prec] and rel_err(d.get_state("FORCE"), fo2) < TOL[prec]
+    assert c.observe()["epot_list"][0] == pytest.approx(o2.observe()["epot_list"][0], rel=1e-11 if prec == 64 else 1e-5)
