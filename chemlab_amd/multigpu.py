@@ -136,7 +136,7 @@ def bench_main(a, spec, rank, local_rank, world):
     ev0 = len(eng.get_events())
     tm0 = eng.timers()
     if not getattr(a, "no_roofline", False):
-        eng.set_option("time_pair_kernel", max(5, a.steps // 256))   # HIP events around the force launches of every N-th timed step
+        eng.set_option("time_pair_kernel", max(10 if a.steps < 200 else 5, a.steps // 256))   # HIP events around the force launches of every N-th timed step
     dist.barrier()
     t0 = time.perf_counter()
     eng.run(a.steps)
