@@ -15,7 +15,7 @@ rs = int(os.environ.get("REACT_STEPS", "0"))
 if rs:
     e.reactions_enable(True); e.run(rs)      # bonds, exclusions and bonded work lists in the rebuild
 e.set_option("debug_stamps", 1)
-e.run(12)
+e.run(int(os.environ.get("STAMP_STEPS", "30")))      # (long enough to hold a list build: they are ~13 steps apart with the list skin)
 e.sync()
 lib = e.api.lib
 lib.chem_debug_dump_rebuild.restype = C.c_int64
