@@ -263,7 +263,7 @@ def late_stage_leg(eng, a, n_reaction_steps=10):
     share = time_share(tm, k)
     ks = kernel_rooflines(a, tm, k / wall, a.precision)
     return dict(value=k / wall, unit="steps/s", steps=k, ms_per_step=1e3 * wall / k, at_step=int(eng.step), reaction_steps_before=int(tm0["reaction_steps"]),
-                bonds=bonds, conversion=bonds / (0.5 * a.n), events=int(len(eng.get_events())), list_rebuilds_timed=int(tm["rebuilds"] - tm0["rebuilds"]),
+                bonds=bonds, conversion=bonds / (0.5 * a.n), events=int(len(eng.get_events())), list_rebuilds_timed=int(tm["rebuilds"] - tm0["rebuilds"]), list_builds_timed=int(tm["list_rebuilds"] - tm0["list_rebuilds"]),
                 device_us_per_step=dict(pair=share["pair"], neighbour_kernel=share["neighbour"], integrate=share["integrate"], bonded=share["bonded"]),
                 kernels=[dict(kernel=q["kernel"], avg_launch_us=q["avg_launch_us"], frac=q["frac"], launches_sampled=q["launches_sampled"]) for q in ks])
 

@@ -175,6 +175,7 @@ struct Ctx {
   virtual void sync() = 0;
   virtual void refresh_timers() {}
   virtual void set_pair_bs(int) {}
+  virtual void set_bond_pass(bool) {}
   virtual int64_t debug_dump(long long*, int64_t) { return 0; }
   virtual void debug_enable(int) {}
   virtual int64_t debug_dump_rebuild(long long*, int64_t) { return 0; }
@@ -251,6 +252,13 @@ template <typename R> struct CtxT : Ctx {
     }
   }
   double inline_K = 0, inline_r0 = 0;
+  // ... and where no particle has more than kBondSlots of them (single domain, fused rebuild), the list build does not look at
+  // the exclusions at all: a streaming pass behind the tiles records the partner slots, the force kernel takes the partners'
+  // pair term out of its sums again (k_pair_tiles bond_mode 2).  Option bond_pass = 0: the list build removes the pairs itself.
+  bool opt_bond_pass = true;
+  void set_bond_pass(bool v) override { opt_bond_pass = v; }
+  DBuf<BondRec<R>> brec_dev; BondRec<R> brec_host{}; bool brec_valid = false;
+  bool bond_by_pass() { return opt_bond_pass && use_fused && !dd_on && bonds_inline() && excl_over == 0; }
   bool bonds_inline() {
     if (!opt_bonds_inline || !(use_fused || (dd_on && use_tiles)) || nbent <= 0 || !harmonic_only || !bonds_excluded) return false;
     // the exclusion set must BE the bond set (bonds are a subset: bonds_excluded; both are duplicate-free): equal counts
@@ -523,11 +531,12 @@ template <typename R> struct CtxT : Ctx {
     a.blockmax = blockmax.p; a.ctl = ctl.p; a.gb = gbar.p; a.box = box; a.act = act;
     a.wgst = dbg_on && wgst.p ? wgst.p : nullptr;
     a.bstart = bstart.p; a.bent = bent.p; a.bwork = bwork.p; a.bj = bj.p; a.nbent = (int)std::min<int64_t>(nbent, 1 << 30);
-    a.bslots = nullptr;
+    a.bslots = nullptr; a.bond_pass = 0;
     if (bonds_inline() && !(sizeof(R) == 8 && want32)) {   // (the exact fp64 builder of the int32 rows locates no slots: ensure_list32 rebuilds again)
-      if (bslots.n < 2 * (size_t)n) bslots.alloc(2 * (size_t)n + 1024);      // two quads (kBondSlots = 8 words) per home particle
+      if (bslots.n < 2 * (size_t)n) bslots.alloc(2 * (size_t)n + 1024);      // two quads (kBondSlots = 8 words) per particle
       a.bslots = bslots.p;
-      if (excl_over == 0) a.nbent = 0;                      // no work list needed; otherwise it holds the owners with > 4 exclusions only
+      a.bond_pass = (bond_by_pass() && !want32) ? 1 : 0;    // (the int32 rows must leave the excluded pairs out: ensure_list32 rebuilds again behind them)
+      if (excl_over == 0) a.nbent = 0;                      // no work list needed; otherwise it holds the owners with > kBondSlots exclusions only
     }
     if (dbg_on || want32) hipLaunchKernelGGL((k_rebuild_fused<R, 512, true>), dim3(fused_grid_diag), dim3(512), list_lds_need(true), stream, a);
     else hipLaunchKernelGGL((k_rebuild_fused<R, 512>), dim3(fused_grid), dim3(512), list_lds_need(false), stream, a);
@@ -1148,6 +1157,17 @@ template <typename R> struct CtxT : Ctx {
   template <bool ENERGY> int launch_pair(V4* fdst, int tpp) {
     const double hs = 0.5 * skin_eff();
     const bool inline_now = bonds_inline();
+    const int bond_mode = inline_now ? (bond_by_pass() ? 2 : 1) : 0;      // (what the LAST rebuild did: both only change where a rebuild is forced)
+    const BondRec<R>* brec = nullptr;
+    if (bond_mode == 2) {      // device copy of what the force launch behind a rebuild needs to record the partner slots (refreshed when a pointer or the box changed)
+      BondRec<R> now{tag.p, excl_start.p, excl_list.p, rtag.p, box};
+      if (!brec_dev.p) brec_dev.alloc(1);
+      if (!brec_valid || std::memcmp(&now, &brec_host, sizeof(now)) != 0) {
+        brec_host = now; brec_valid = true;
+        HIPCHK(hipMemcpyAsync(brec_dev.p, &brec_host, sizeof(now), hipMemcpyHostToDevice, stream));
+      }
+      brec = brec_dev.p;
+    }
     if (use_tiles) {
       // which tiles: all (default), or the interior / boundary subset of a slab (see TileSub)
       const int ntxy = tile_ntx(box.nc[0], box.xs_nb, box.xs_w) * ((box.nc[1] + HY - 1) / HY);
@@ -1158,7 +1178,7 @@ template <typename R> struct CtxT : Ctx {
       if (nsub <= 0) return 0;
 #define LTD(T, M, B, D) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M, D>), dim3(nsub), dim3(B), pair_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
                                  nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, pair_guard, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr, ts, pair_da, \
-                                 (!ENERGY && inline_now) ? (const uint4*)bslots.p : (const uint4*)nullptr, inline_K, inline_r0)
+                                 (inline_now && (!ENERGY || bond_mode == 2)) ? bslots.p : (uint4*)nullptr, inline_K, inline_r0, bond_mode, act, brec)
 #define LT(T, M, B) LTD(T, M, B, false)
       // diagnostics (options debug_stamps / ablate): one instantiation, one lane per particle, 512 threads
 #define LTB(T, M) do { if ((dbg_on || opt_ablate) && !ENERGY) { if (T != 1 || pair_bs != 512) throw ChemError(CHEM_EINVAL, "debug_stamps / ablate need tpp=1 and pair_block=512"); LTD(1, M, 512, true); } \
@@ -1454,7 +1474,7 @@ template <typename R> struct CtxT : Ctx {
     want32 = true;
     rebuild_now();
     want32 = false;
-    if (sizeof(R) == 8 && bonds_inline()) rebuild_now();   // same order, same rows; the regular builder records the bonded partners' slots again
+    if (bonds_inline() && (sizeof(R) == 8 || bond_by_pass())) rebuild_now();   // same order, same rows; the regular build: partner slots again (fp64), excluded pairs back in the force list (bond pass)
   }
 
   // ---- reactions ----------------------------------------------------------------------
@@ -2541,6 +2561,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "ablate") CTX.opt_ablate = (int)value;
   else if (k == "rebuild_criterion") { CTX.opt_criterion = value != 0 ? 1 : 0; CTX.resort = true; CTX.geom_dirty = true; }
   else if (k == "bonds_inline") { CTX.opt_bonds_inline = value != 0; CTX.resort = true; }
+  else if (k == "bond_pass") { CTX.set_bond_pass(value != 0); CTX.resort = true; }
   else if (k == "bucket_cap") { CTX.opt_bucket_cap = (int)value; CTX.geom_dirty = true; }
   else if (k == "tile_split") { CTX.opt_tile_split = (int)value; CTX.geom_dirty = true; CTX.resort = true; }
   else if (k == "list_skin") { CTX.opt_list_skin = value; CTX.geom_dirty = true; CTX.resort = true; }

@@ -1609,7 +1609,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
     const int ti = (int)x4[p].w & 15;                 // home cells carry no periodic shift: x4[p] is the staged particle
     const CHEM_LDS unsigned int* tmrow = tmask + ti * L.nwords;
     int e0 = 0, e1 = 0;
-    if (has_excl) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }
+    if (has_excl && ablate != 5) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }      // (ablate 5, diagnostic: exclusions ignored)
     int cnt = 0, cnt16 = 0;
     int* row32 = nlist ? nlist + (size_t)p * S : nullptr;
     // Exclusions without leaving the plain path (single domain): the few excluded partners of a particle are located
@@ -1649,7 +1649,7 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
     // no bonded table is consulted.  Located partners (<= 4 exclusions) are written here; on the generic path (5..8 exclusions,
     // or int32 rows wanted) every excluded hit is recorded as it is met in the sweep below.  More than kBondSlots exclusions:
     // the particle's bonds stay with the work list.
-    unsigned int* const bsw = bslots ? reinterpret_cast<unsigned int*>(bslots) + (size_t)(hbase + q) * kBondSlots : nullptr;
+    unsigned int* const bsw = bslots ? reinterpret_cast<unsigned int*>(bslots) + (size_t)p * kBondSlots : nullptr;      // (indexed by the particle's place in the sorted arrays)
     int nbw = 0;
     const bool bond_rec = bsw && !fastx && e1 > e0 && e1 - e0 <= kBondSlots;      // generic path records while sweeping
     if (bsw && (fastx || e1 == e0)) {
@@ -1908,6 +1908,53 @@ struct TileSub { int base1, n1, base2; };
 // gathered step maxima (same inputs, same arithmetic: same result), workgroup 0 publishes it -- control block, pinned
 // host words the host polls -- and all leave at once when a rebuild is due: no one-block decision launch between the
 // halo exchange and the forces.  The accumulated distance is double-buffered by step parity (read [par], written [par^1]).
+// LDS slot of particle g (sorted index, position xg) in the staged image of the tile described by T; -1: outside its stencil.
+// (cell of g by the binning arithmetic on the same bits, relative to the tile's first home cell with the periodic wrap)
+template <typename R>
+__device__ __forceinline__ int tile_partner_slot(const TileLDS<R>& T, int g, const Vec4<R>& xg, const Box<R>& bx, DevCtl* ctl) {
+  const int nx = bx.nc[0], ny = bx.nc[1], nz = bx.nc[2], org = T.geom[6];
+  int kx = pos_cell(xg.x, 0, nx, bx) - (org & 1023) + 1, ky = pos_cell(xg.y, 1, ny, bx) - ((org >> 10) & 1023) + 1, kz = pos_cell(xg.z, 2, nz, bx) - (org >> 20) + 1;
+  kx += kx < 0 ? nx : 0; kx -= kx >= nx ? nx : 0;
+  ky += ky < 0 ? ny : 0; ky -= ky >= ny ? ny : 0;
+  kz += kz < 0 ? nz : 0; kz -= kz >= nz ? nz : 0;
+  if (kx < T.geom[0] + 2 && ky < T.geom[1] + 2 && kz < T.geom[2] + 2) {
+    const int rr = kz * SY + ky, off = g - T.cellg[rr][kx];
+    if (off >= 0 && off < T.celloff[rr][kx + 1] - T.celloff[rr][kx]) return T.rowoff[rr] + T.celloff[rr][kx] + off;
+    ctl->excl_slot_error = 1;
+  }
+  return -1;
+}
+// what the force kernel needs to record the bonded partners' slots itself (bond_mode 2, launch of a rebuild step)
+template <typename R> struct BondRec { const int *tag, *excl_start, *excl_list, *rtag; Box<R> box; };
+// The force launch behind a rebuild records, for home particle p of the tile described by *T, the LDS slots of its bonded
+// (= excluded) partners: tag -> exclusion row -> partner index -> partner position -> cell -> slot through the tile tables;
+// written out for the launches up to the next rebuild, first quad returned.  A real function call on purpose: inlined, its
+// registers cost the hot loop of k_pair_tiles 84-116 bytes of spills per lane; it runs once per list lifetime.
+template <typename R>
+__device__ __noinline__ uint4 bond_record(const TileLDS<R>* T, int p, const BondRec<R>* __restrict__ brec_p, const Vec4<R>* __restrict__ x4,
+                                          uint4* __restrict__ bslots, DevCtl* ctl) {
+  const BondRec<R>& brec = *brec_p;
+  unsigned int w[kBondSlots];
+#pragma unroll
+  for (int k = 0; k < kBondSlots; ++k) w[k] = ~0u;
+  const int tg = brec.tag[p];
+  const int e0 = brec.excl_start[tg], e1 = brec.excl_start[tg + 1];
+  if (e1 > e0 && e1 - e0 <= kBondSlots) {
+#pragma unroll
+    for (int k = 0; k < kBondSlots; ++k) {
+      if (e0 + k >= e1) break;
+      const int g = brec.rtag[brec.excl_list[e0 + k]];
+      const int sl = g >= 0 ? tile_partner_slot<R>(*T, g, x4[g], brec.box, ctl) : -1;
+      if (sl < 0) ctl->bond_slot_miss = 1;      // every bonded partner sits inside the stencil (bond length << cell edge)
+      else w[k] = (unsigned int)sl;
+    }
+  }
+  const uint4 q0 = make_uint4(w[0], w[1], w[2], w[3]);
+  bslots[2 * (size_t)p] = q0;
+  if (w[3] != ~0u) bslots[2 * (size_t)p + 1] = make_uint4(w[4], w[5], w[6], w[7]);      // (only read behind a full first quad)
+  return q0;
+}
+
 struct DecideArgs { const double* gathered; int n; volatile int* host_flag; int ticket, par, criterion; double half_skin_ref; };
 
 // (fp64: the 32-byte-per-slot image allows one or two workgroups per CU anyway -- 128 registers instead of 80 and spills)
@@ -1921,8 +1968,9 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
                                                    const PairCore<R>* __restrict__ pcore, const PairExt<R>* __restrict__ pext,
                                                    int ntypes, const Vec4<R>* __restrict__ tab, UniLJ uni, double* __restrict__ eout,
                                                    double half_skin, DevCtl* ctl, int guard, int ablate, long long* __restrict__ dbg, TileSub sub_,
-                                                   DecideArgs da = DecideArgs{}, const uint4* __restrict__ bslots = nullptr,
-                                                   double bond_K = 0.0, double bond_r0 = 0.0) {
+                                                   DecideArgs da = DecideArgs{}, uint4* __restrict__ bslots = nullptr,
+                                                   double bond_K = 0.0, double bond_r0 = 0.0, int bond_mode = 0, ActMask bact = ActMask{},
+                                                   const BondRec<R>* __restrict__ brec = nullptr) {      // (device copy: by value it was spilled to every lane's stack at kernel start)
   constexpr bool LJONLY = MODE >= 1;
 #ifndef CHEM_NCH
 #define CHEM_NCH 3
@@ -1978,6 +2026,7 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
   int p = -1, cnt = 0, hslot = 0, qq = 0;
   uint4 pkv[NCH];
   uint4 bwv = make_uint4(~0u, ~0u, ~0u, ~0u);
+  const bool bond_rec = bslots && brec && bond_mode == 2 && ctl->need_rebuild != 0;      // (uniform: set by the rebuild of THIS step, cleared by the next idle decision)
   auto locate = [&](int q) {
     int sgi = 0;
 #pragma unroll
@@ -1987,7 +2036,7 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
     const int hr = (sgi / HY + 1) * SY + (sgi % HY + 1);
     hslot = T.rowoff[hr] + T.celloff[hr][1] + inrun;      // the home particle's own slot in the staged tile
     cnt = nnh[hbase + q];
-    if (!ENERGY && bslots) bwv = bslots[2 * (size_t)(hbase + q)];   // (inline bonds: first quad, issued with the list chunks, consumed after the pair loop)
+    if (bslots && !bond_rec) bwv = bslots[2 * (size_t)p];   // (inline bonds: first quad, issued with the list chunks, consumed after the pair loop)
 #pragma unroll
     for (int c = 0; c < NCH; ++c)                           // the tile's region is always allocated: safe before cnt is known
       pkv[c] = (sub + c * TPP) * 8 < S16 ? nt_load_u4(&reg[(size_t)(sub + c * TPP) * nhome + q]) : make_uint4(0, 0, 0, 0);
@@ -2094,10 +2143,16 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
         }
       }
       fx += (R)fxy.x; fy += (R)fxy.y;      // (packed x/y accumulators of the uniform-LJ fp32 path; zero otherwise)
-      if (!ENERGY && bslots) {
+      if (bslots && sub == 0) {
         // Inline harmonic bonds (FixedPairListHarmonic, gromacs_topology.py:949-961; reaction bonds reaction_setup.py:449-467):
-        // the partners' LDS slots were recorded by the list build, the geometry comes from the staged image (tile-local
-        // coordinates: 2.4e-7 in the fp32 build, exact in fp64) -- no bonded launch, no second pass over f4
+        // the LDS slots of the bonded (= excluded) partners are recorded at every rebuild, the geometry comes from the staged
+        // image (tile-local coordinates: 2.4e-7 in the fp32 build, exact in fp64) -- no bonded launch, no second pass over f4.
+        // bond_mode 1: the list build removed the excluded pairs from the force list (decomposed path) -- add the bonds.
+        // bond_mode 2: the list build IGNORED the exclusions (single domain: locating the partners inside the list phase cost
+        //   196 us of a 709-us late-stage rebuild, profiles/round3_rebuild_ablation.txt; a streaming pass behind it records the
+        //   slots instead) -- the partners' pair term is in the sums above: take it out again, then add the bonds.  An excluded
+        //   pair within the cutoff now was within the list radius at the build, i.e. it IS in the list if its type pair is active.
+        if (bond_rec) bwv = bond_record<R>(&T, p, brec, x4, bslots, ctl);      // (the launch behind a rebuild, bond_mode 2)
         const R m2K = (R)(-2.0 * bond_K), r0b = (R)bond_r0;              // (one parameter set: kernel arguments, no table)
         auto bond_quad = [&](const uint4 bq) {
           const unsigned int bws[4] = {bq.x, bq.y, bq.z, bq.w};
@@ -2106,15 +2161,32 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
             if (bws[k] == ~0u) continue;
             const unsigned int sl = bws[k];
             Vec4<R> xj;
-            if constexpr (D3) xj = lds_gather3d(sx, sl); else xj = sx[sl];
+            if constexpr (D3) { xj = lds_gather3d(sx, sl); xj.w = (R)d3_types<R>(sx, CAP)[sl]; } else xj = sx[sl];
             const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
-            const R r = sqrt_r(dx * dx + dy * dy + dz * dz);
-            const R ffb = m2K * (r - r0b) / r;                             // U = K (r - r0)^2
-            fx += ffb * dx; fy += ffb * dy; fz += ffb * dz;
+            const R r2 = dx * dx + dy * dy + dz * dz;
+            if (bond_mode == 2) {
+              if (MODE == 2 && !ENERGY) {
+                if (r2 <= u_rc2 && ((bact.row[(int)xi.w & 15] >> ((int)xj.w & 15)) & 1u)) {
+                  const R r2i = rcp_r(r2), r6i = r2i * r2i * r2i;
+                  const R ffp = r6i * (u_lj1 * r6i - u_lj2) * r2i;
+                  fx -= ffp * dx; fy -= ffp * dy; fz -= ffp * dz;
+                }
+              } else {
+                R tx = 0, ty = 0, tz = 0; double te1 = 0, te2 = 0, tv = 0;
+                const int pidx = pbase + (int)xj.w;
+                pair_accum<R, ENERGY, LJONLY>(spc[pidx], pext, pidx, tab, r2, dx, dy, dz, tx, ty, tz, te1, te2, tv);
+                fx -= tx; fy -= ty; fz -= tz; e_lj -= te1; e_tab -= te2; vir -= tv;
+              }
+            }
+            if (!ENERGY) {
+              const R r = sqrt_r(r2);
+              const R ffb = m2K * (r - r0b) / r;                           // U = K (r - r0)^2
+              fx += ffb * dx; fy += ffb * dy; fz += ffb * dz;
+            }
           }
         };
         bond_quad(bwv);
-        if (bwv.w != ~0u) bond_quad(bslots[2 * (size_t)(hbase + qq) + 1]);   // five to eight bonds: the second quad (rare)
+        if (bwv.w != ~0u) bond_quad(bslots[2 * (size_t)p + 1]);   // five to eight bonds: the second quad (rare)
       }
     }
     if (TPP > 1) {
@@ -2477,7 +2549,10 @@ template <typename R> struct FusedArgs {
   unsigned short* nl16; int *nnh, *nlist, *nn;
   unsigned long long* blockmax; DevCtl* ctl; GridBar* gb;
   const int* bstart; const BondedEntry* bent; int4 *bwork, *bj; int nbent;
-  uint4* bslots;         // inline bonds (non-null: the list build records the bonded partners' LDS slots, no work list is built)
+  uint4* bslots;         // inline bonds (non-null: the bonded partners' LDS slots are recorded, eight words per particle)
+  int bond_pass;         // 1: the list build ignores the exclusions (= bonds); the force launch of the rebuild step records the partner
+                         //    slots itself and every force launch takes the partners' pair term out again (k_pair_tiles bond_mode 2);
+                         //    0: the list build removes the excluded pairs and records their slots
   Box<R> box; ActMask act;
   long long* wgst;   // diagnostics (option debug_stamps=2): 8 wall-clock stamps per workgroup of the last rebuilding launch
 };
@@ -2687,9 +2762,9 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
         __syncthreads();
         if (ablate == 1) { for (int q = t; q < T.geom[4]; q += BS) a.nnh[T.geom[5] + q] = 0; }
         else
-        dev_nlist_tile_f32<R, BS>(T, chem_dyn_lds, L, a.tago, (float)a.rl2, a.excl_start, a.excl_list, a.has_excl, a.nl16, a.S, a.nnh,
+        dev_nlist_tile_f32<R, BS>(T, chem_dyn_lds, L, a.tago, (float)a.rl2, a.excl_start, a.excl_list, a.bond_pass ? 0 : a.has_excl, a.nl16, a.S, a.nnh,
                                (DIAG && a.want32) ? a.nlist : (int*)nullptr, a.S, a.nn, ctl, &a.box, a.rtag, a.x4o, ablate, (float)a.rl2_rows,
-                               a.bslots);
+                               a.bond_pass ? (uint4*)nullptr : a.bslots);
       } else {
         tile_fill<R, BS, true>(T, sx, a.CAP, a.x4o, 1);
         __syncthreads();

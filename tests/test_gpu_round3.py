@@ -384,15 +384,28 @@ def test_inline_bonds_equal_the_bonded_kernel(make_gpu, make_oracle, prec):
     spec2 = dict(spec, pos=a.get_state("POS"), vel=a.get_state("VEL"), types=a.get_state("TYPE"), state=a.get_state("STATE"))
     spec2["lists"] = [dict(arity=2, kind="HARMONIC", params=[30.0, 0.97], ids=a.get_list(ha["reaction_bonds"]))]
     spec2["exclusions"] = a.get_exclusions()
-    c, d, o2 = make_gpu(prec), make_gpu(prec), make_oracle()
-    for e in (c, d, o2):
+    # c: the default (the list build ignores the exclusions, a pass behind it records the partner slots, the force kernel
+    # takes the partners' pair term out again); c1: the list build removes the excluded pairs and records the slots itself;
+    # d: no inline bonds at all
+    c, c1, d, o2 = make_gpu(prec), make_gpu(prec), make_gpu(prec), make_oracle()
+    for e in (c, c1, d, o2):
         W.apply(spec2, e, thermostat=False, reactions=False)
     d.set_option("bonds_inline", 0)
-    c.run(0); d.run(0); o2.run(0)
-    fo2 = o2.get_state("FORCE")
-    assert rel_err(c.get_state("FORCE"), fo2) < TOL[prec] and rel_err(d.get_state("FORCE"), fo2) < TOL[prec]
+    c1.set_option("bond_pass", 0)
+    c.run(0); c1.run(0); d.run(0); o2.run(0)
+    fo2, oo2 = o2.get_state("FORCE"), o2.observe()
+    for e in (c, c1, d):
+        assert rel_err(e.get_state("FORCE"), fo2) < TOL[prec]
+        oe = e.observe()
+        assert oe["epot_list"][0] == pytest.approx(oo2["epot_list"][0], rel=1e-11 if prec == 64 else 1e-5)
+        assert oe["epot_lj"] == pytest.approx(oo2["epot_lj"], rel=1e-11 if prec == 64 else 2e-6)      # (excluded pairs: not in the energy either)
+        assert oe["virial_nb"] == pytest.approx(oo2["virial_nb"], rel=1e-10 if prec == 64 else 2e-5)
     assert rel_err(c.get_state("FORCE"), d.get_state("FORCE")) < (1e-12 if prec == 64 else 1e-5)
-    assert c.observe()["epot_list"][0] == pytest.approx(o2.observe()["epot_list"][0], rel=1e-11 if prec == 64 else 1e-5)
+    assert rel_err(c1.get_state("FORCE"), d.get_state("FORCE")) < (1e-12 if prec == 64 else 1e-5)
+    if prec == 64:
+        assert np.array_equal(c.get_verlet_pairs(), o2.get_verlet_pairs())      # (the int32 rows leave the excluded pairs out in any mode)
+        c.run(0)
+        assert rel_err(c.get_state("FORCE"), fo2) < TOL[prec]                   # ... and the force list is the regular one again behind them
 
 
 @pytest.mark.parametrize("narm", [6, 10])
