@@ -83,8 +83,8 @@ def test_dense_system_leaves_the_lds_tiles_and_stays_correct(make_gpu, make_orac
                 kT=1.0, gamma=0.0, seed=3, exclusions=np.stack([np.arange(1, 2001, 2), np.arange(2, 2002, 2)], 1))
     g, o, _ = both(make_gpu, make_oracle, spec, prec, thermostat=False)
     g.run(0); o.run(0)
-    # (soft system: the largest force is ~1, i.e. the fp32 coordinate ulp weighs 2x more against it than in the LJ melts)
-    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < (TOL[64] if prec == 64 else 1e-4)
+    # (soft system: the largest force is ~1, so the rounding of the staged coordinates weighs more against it than in the LJ melts)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < (TOL[64] if prec == 64 else 2e-5)
     if prec == 64:
         assert np.array_equal(g.get_verlet_pairs(), o.get_verlet_pairs())
     g.run(20); o.run(20)
