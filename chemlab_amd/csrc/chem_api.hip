@@ -1160,7 +1160,10 @@ template <typename R> struct CtxT : Ctx {
     const int bond_mode = inline_now ? (bond_by_pass() ? 2 : 1) : 0;      // (what the LAST rebuild did: both only change where a rebuild is forced)
     const BondRec<R>* brec = nullptr;
     if (bond_mode == 2) {      // device copy of what the force launch behind a rebuild needs to record the partner slots (refreshed when a pointer or the box changed)
-      BondRec<R> now{tag.p, excl_start.p, excl_list.p, rtag.p, box};
+      BondRec<R> now;
+      std::memset(&now, 0, sizeof(now));      // (compared bytewise below: no indeterminate padding)
+      now.tag = tag.p; now.excl_start = excl_start.p; now.excl_list = excl_list.p; now.rtag = rtag.p;
+      std::memcpy(&now.box, &box, sizeof(box));
       if (!brec_dev.p) brec_dev.alloc(1);
       if (!brec_valid || std::memcmp(&now, &brec_host, sizeof(now)) != 0) {
         brec_host = now; brec_valid = true;

@@ -1929,7 +1929,10 @@ template <typename R> struct BondRec { const int *tag, *excl_start, *excl_list, 
 // The force launch behind a rebuild records, for home particle p of the tile described by *T, the LDS slots of its bonded
 // (= excluded) partners: tag -> exclusion row -> partner index -> partner position -> cell -> slot through the tile tables;
 // written out for the launches up to the next rebuild, first quad returned.  A real function call on purpose: inlined, its
-// registers cost the hot loop of k_pair_tiles 84-116 bytes of spills per lane; it runs once per list lifetime.
+// registers cost the hot loop of k_pair_tiles 84-116 bytes of spills per lane; it runs once per list lifetime.  The partners are
+// walked one after the other (the launch behind a rebuild takes 128 us instead of 79): issuing each level of the chain for
+// four partners at once needs more registers in the callee, and THAT slowed every launch (same box, melt / late stage:
+// 62.7 / 85.8 us -> 66.7 / 93.8 us per force launch; tools/ab_late_lib.sh).
 template <typename R>
 __device__ __noinline__ uint4 bond_record(const TileLDS<R>* T, int p, const BondRec<R>* __restrict__ brec_p, const Vec4<R>* __restrict__ x4,
                                           uint4* __restrict__ bslots, DevCtl* ctl) {
