@@ -1300,17 +1300,6 @@ __device__ __forceinline__ void tile_fill(const TileLDS<R>& T, Vec4<R>* const sx
   }
 }
 
-// Experiment (CHEM_FILL_CALL): the staging of the force kernel as a real function call, so that its ~50 registers do not
-// compete with the list chunks a lane preloads in front of it (NCH); the pointers stay in the LDS address space.
-#ifndef CHEM_FILL_CALL
-#define CHEM_FILL_CALL 0
-#endif
-#define CHEM_LDS_ __attribute__((address_space(3)))
-template <typename R, int BS, bool D3>
-__device__ __noinline__ void tile_fill_call(CHEM_LDS_ const TileLDS<R>* T, CHEM_LDS_ Vec4<R>* sx, int CAP, const Vec4<R>* __restrict__ x4) {
-  tile_fill<R, BS, false, D3>(*(const TileLDS<R>*)T, (Vec4<R>*)sx, CAP, x4, 0);
-}
-
 // List build, fp32: LDS layout of one staged tile (inside the same dynamic LDS block the force kernel uses for its
 // float4 image -- 12 + ntypes/8 bytes per slot instead of 16):
 //   img   groups of FOUR slots in SoA order, 64 bytes (+16 of padding, kGrpF) per group: u0..u3 | v0..v3 | w0..w3 | q0..q3 with (u,v,w) the
@@ -2057,11 +2046,7 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
   };
   if (slice < nhome) locate(slice);
   constexpr bool D3 = sizeof(R) == 8;     // fp64: 24-byte slots + type bytes (see tile_fill)
-#if CHEM_FILL_CALL
-  if (!DIAG || ablate != 2) tile_fill_call<R, BS, D3>((CHEM_LDS const TileLDS<R>*)&T, (CHEM_LDS Vec4<R>*)sx, CAP, x4);
-#else
   if (!DIAG || ablate != 2) tile_fill<R, BS, false, D3>(T, sx, CAP, x4, 0);
-#endif
   __syncthreads();
   if (DIAG && ablate == 1) return;   // diagnostic: staging only
   if (DIAG && dbg) st2 = wall_clock64();
