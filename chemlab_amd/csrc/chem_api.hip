@@ -278,6 +278,7 @@ template <typename R> struct CtxT : Ctx {
   // joined (and uploaded) before the next reaction scan and before any other API call
   std::thread label_thr; bool labels_pending = false; std::exception_ptr label_err;
   std::vector<std::pair<int32_t, int32_t>> label_bonds; std::vector<int32_t> label_touched;
+  std::vector<int> label_seen_lists;      // bonded list of every bond in label_bonds whose de-duplication key the thread still has to insert
   void join_async() override {
     join_thread();
     sync_type_mirrors();      // any API call other than chem_run sees current type/mass/charge mirrors
@@ -836,6 +837,7 @@ template <typename R> struct CtxT : Ctx {
   // staging vectors: milliseconds each) is paid here, once, when a run with reactions starts -- sized for one bond
   // per particle, beyond that they grow geometrically as before.
   bool react_tables_reserved = false;
+  std::vector<Candidate> bond_ev;       // bond-forming events of a reaction step in canonical order
   std::vector<Candidate> radix_tmp;     // scratch of the event sort (kept: a fresh 6 MB vector per step is 1.5 ms of page faults)
   void reserve_reaction_tables() {
     if (react_tables_reserved) return;
@@ -846,7 +848,7 @@ template <typename R> struct CtxT : Ctx {
       HostList& l = top.lists[d.bond_list];
       l.seen.reserve(l.seen.used + nt); l.ent.reserve(l.ent.size() + 2 * nt);
     }
-    radix_tmp.reserve(nt / 2 + 1024);
+    radix_tmp.reserve(nt / 2 + 1024); bond_ev.reserve(nt / 2 + 1024);
     stage_ne.reserve(nt / 2 * per + 1024); stage_nl.reserve(nt / 2 * per + 1024); stage_ep.reserve(nt / 2 * per + 1024);
     grow(fent, fent_n, fent_n + nt * per, stream); grow(flist, fent_n, fent_n + nt * per, stream);
     grow(epairs, epairs_n, epairs_n + nt * per, stream);
@@ -1663,13 +1665,18 @@ template <typename R> struct CtxT : Ctx {
     // the order of the bond lists); the event log itself is put in canonical order lazily
     // by chem_get_events.
     auto ekey = [](const Candidate& p) { return ((uint64_t)(uint32_t)std::min(p.a, p.b) << 32) | (uint32_t)std::max(p.a, p.b); };
+    // bond-forming events in canonical order, extracted into a heap buffer; the pinned event array stays as the device wrote it.
+    // (0.6-0.8 ms at 2.5e5 events, as partitioning and sorting in place was: ONE pass over 6 MB the GPU has just written
+    //  through PCIe is most of it -- a device-side compaction of the bond-forming events would be the next step)
+    std::vector<Candidate>& bev = bond_ev;
+    bev.clear();
+    for (const Candidate& e : hev) if (!reactions[e.r].is_virtual) bev.push_back(e);
     {
-      auto mid = std::partition(hev.begin(), hev.end(), [&](const Candidate& p) { return !reactions[p.r].is_virtual; });
       // A particle takes part in at most one event per reaction step, so min(a,b) alone is a unique
       // key: LSD radix sort (3 x 11 bits) instead of a comparison sort of 10^5 events.
-      const size_t m = (size_t)(mid - hev.begin());
+      const size_t m = bev.size();
       if (radix_tmp.size() < m) radix_tmp.resize(m);
-      Candidate* src = hev.data(); Candidate* dst = radix_tmp.data();
+      Candidate* src = bev.data(); Candidate* dst = radix_tmp.data();
       for (int pass = 0; pass < 3; ++pass) {
         size_t cnt[2049] = {0};
         const int sh = 11 * pass;
@@ -1678,11 +1685,12 @@ template <typename R> struct CtxT : Ctx {
         for (size_t k = 0; k < m; ++k) dst[cnt[((uint32_t)std::min(src[k].a, src[k].b) >> sh) & 2047u]++] = src[k];
         std::swap(src, dst);
       }
-      if (src != hev.data()) std::copy(src, src + m, hev.data());
+      if (src != bev.data()) std::copy(src, src + m, bev.data());
       bool unique = true;
-      for (size_t k = 1; k < m && unique; ++k) unique = std::min(hev[k - 1].a, hev[k - 1].b) != std::min(hev[k].a, hev[k].b);
-      if (!unique) std::sort(hev.begin(), mid, [&](const Candidate& p, const Candidate& q) { return ekey(p) < ekey(q); });
+      for (size_t k = 1; k < m && unique; ++k) unique = std::min(bev[k - 1].a, bev[k - 1].b) != std::min(bev[k].a, bev[k].b);
+      if (!unique) std::sort(bev.begin(), bev.end(), [&](const Candidate& p, const Candidate& q) { return ekey(p) < ekey(q); });
     }
+    trc.lap("bond events");
     std::vector<std::pair<int32_t, int32_t>> newbonds;
     newbonds.reserve(hev.size());
     bool types_changed = false;
@@ -1710,13 +1718,27 @@ template <typename R> struct CtxT : Ctx {
     std::exception_ptr mirror_err;
     // (measured, round 3: inserting by hash shards on helper threads -- a persistent pool of 1..3 -- made this loop SLOWER,
     //  1.0-1.7 ms -> 2.0-3.9 ms for 2.4-4.3e4 new bonds on the 2-socket host: the table lives on the caller's NUMA node)
-    for (size_t k = 0; k < hev.size(); ++k) {
-      const Candidate& e = hev[k];
+    // Where every bond is an excluded pair (bonds_excluded: checked at the last full upload, kept by construction since) and the
+    // scan honours the exclusions, a candidate pair cannot be bonded already, and a particle takes part in one event per step:
+    // every bond-forming event is a new bond.  The insertion into the list's de-duplication set -- one cache miss per bond in a
+    // table of 10^6, 0.2 -> 1.7 ms of this step as the conversion grows -- then moves to the bookkeeping thread.
+    const bool defer_seen = bonds_excluded && has_excl && !top.spawns_tuples() && nb_rules.empty();
+    label_seen_lists.clear();
+    for (size_t k = 0; defer_seen && k < bev.size(); ++k) {
+      const Candidate& e = bev[k];
       const chem_reaction_desc& d = reactions[e.r];
-      if (d.is_virtual) break;   // bond-forming events were partitioned to the front
-      if (k + 24 < hev.size() && !reactions[hev[k + 24].r].is_virtual) {   // the de-duplication set is a 10^6-entry hash table: hide its misses
-        int32_t tp[2] = {hev[k + 24].a, hev[k + 24].b};
-        top.lists[reactions[hev[k + 24].r].bond_list].seen.prefetch(tuple_key(tp, 2));
+      HostList& l = top.lists[d.bond_list];
+      const int32_t t[2] = {e.a, e.b};
+      l.ent.insert(l.ent.end(), t, t + 2);
+      newbonds.emplace_back(e.a, e.b);
+      label_seen_lists.push_back(d.bond_list);
+    }
+    for (size_t k = 0; !defer_seen && k < bev.size(); ++k) {
+      const Candidate& e = bev[k];
+      const chem_reaction_desc& d = reactions[e.r];
+      if (k + 24 < bev.size()) {   // the de-duplication set is a 10^6-entry hash table: hide its misses
+        int32_t tp[2] = {bev[k + 24].a, bev[k + 24].b};
+        top.lists[reactions[bev[k + 24].r].bond_list].seen.prefetch(tuple_key(tp, 2));
       }
       int32_t t[2] = {e.a, e.b};
       if (top.list_insert(top.lists[d.bond_list], t)) newbonds.emplace_back(e.a, e.b);
@@ -1778,6 +1800,10 @@ template <typename R> struct CtxT : Ctx {
         label_thr = std::thread([this, log0, log_ev, log_n, log_step, intra_flags] {
           try {
             if (log_n) append_events(log_ev, log_n, log_step, intra_flags);
+            for (size_t k = 0; k < label_seen_lists.size(); ++k) {      // (deferred de-duplication keys of this step's bonds)
+              const int32_t t[2] = {label_bonds[k].first, label_bonds[k].second};
+              top.lists[label_seen_lists[k]].seen.insert(tuple_key(t, 2));
+            }
             top.link_new_bonds(label_bonds); top.merge_new_bonds(label_bonds, label_touched);
             // rows + pair count; the log already holds these pairs
             for (auto& e : label_bonds) { if (HostTopology::sorted_insert(top.excl[e.first], e.second)) { HostTopology::sorted_insert(top.excl[e.second], e.first); ++top.n_excl_pairs; } }
