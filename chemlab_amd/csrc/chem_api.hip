@@ -523,7 +523,7 @@ template <typename R> struct CtxT : Ctx {
     a.half_skin = 0.5 * skin_eff(); a.rl2 = (R)((rc + skin_eff()) * (rc + skin_eff()));
     a.half_skin_ref = 0.5 * skin; a.rl2_rows = (R)((rc + skin) * (rc + skin));
     a.istep = step;
-    a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = x0.p;
+    a.x4 = x4.p; a.v4 = v4.p; a.x4o = x4o.p; a.v4o = v4o.p; a.x0 = opt_criterion ? x0.p : nullptr;      // (reference positions: only the displacement criterion reads them -- 16 MB of writes per rebuild otherwise)
     a.tag = tag.p; a.tago = tago.p; a.rtag = rtag.p; a.img4 = img4.p; a.img4o = img4o.p;
     a.cell_cnt = cell_cnt.p; a.cell_of = cell_of.p; a.slot_of = slot_of.p; a.cell_start = cell_start.p; a.cell_loc = cell_loc.p;
     a.cell_sub = cell_sub.p; a.cell_n = cell_n.p; a.bucket = bucket.p; a.bcap = bcap; a.btot = seg_tot.p; a.perm = perm.p; a.tn = tile_n.p; a.tloc = tile_loc.p; a.tbtot = tseg_tot.p;
