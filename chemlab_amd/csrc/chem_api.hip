@@ -199,7 +199,8 @@ template <typename R> struct CtxT : Ctx {
   static constexpr size_t kTileLdsBudget = 150 * 1024;   // of 160 KB per CU: the rest is the kernels' static __shared__ (tile tables, scan scratch)
   // reaction scan: the staged image + 4 bytes per slot of role words (k_react_roles)
   size_t scan_lds_bytes() const { return scan_roles_offset(tile_cap, sizeof(V4)) + (size_t)(tile_cap + 1) * sizeof(unsigned int); }
-  size_t tile_lds_need() const { return std::max(std::max(std::max(tile_lds_bytes(), pair_lds_bytes()), list_lds_need()), scan_lds_bytes()); }
+  bool scan_roles_staged() const { return scan_lds_bytes() <= kTileLdsBudget; }      // (otherwise the scan reads the role words from global memory)
+  size_t tile_lds_need() const { return std::max(std::max(tile_lds_bytes(), pair_lds_bytes()), list_lds_need()); }
   size_t list_lds_need(bool exact_rows = true) const {
     const size_t lb = list_lds_bytes(tile_cap, kMaxTypes);
     return (sizeof(R) == 4 || exact_rows) ? std::max(tile_lds_bytes(), lb) : lb;
@@ -548,7 +549,7 @@ template <typename R> struct CtxT : Ctx {
     const int bytes = (int)tile_lds_bytes();
 #define SETA(K) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, bytes))
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_nlist_tiles<R, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)list_lds_need()));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_react_scan_tiles<R, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes()));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_react_scan_tiles<R, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(scan_roles_staged() ? scan_lds_bytes() : tile_lds_bytes())));
 #define SETB(T, E, M) SETA((k_pair_tiles<R, T, E, 256, M>)); SETA((k_pair_tiles<R, T, E, 512, M>)); SETA((k_pair_tiles<R, T, E, 1024, M>)); \
                       if (T == 1 && !E) SETA((k_pair_tiles<R, 1, false, 512, M, true>))
 #define SETT(E, M) SETB(1, E, M); SETB(2, E, M); SETB(4, E, M); SETB(8, E, M)
@@ -1559,9 +1560,9 @@ template <typename R> struct CtxT : Ctx {
       tile_cnt.alloc(ntiles + 1); tile_off.alloc(ntiles + 1);
       if (scan_role.n < (size_t)acap()) scan_role.alloc((size_t)acap() + 1024);
       hipLaunchKernelGGL(k_react_roles<R>, dim3(std::min(cdiv(acap(), 256), 4096)), dim3(256), 0, stream, acap(), nglob, x4.p, tag.p, state.p, rs_dev.p, scan_role.p);
-      hipLaunchKernelGGL((k_react_scan_tiles<R, 512>), dim3(ntiles), dim3(512), scan_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, state.p,
+      hipLaunchKernelGGL((k_react_scan_tiles<R, 512>), dim3(ntiles), dim3(512), scan_roles_staged() ? scan_lds_bytes() : tile_lds_bytes(), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, state.p,
                          res_id.p, mol_id.p, boxd, rs_dev.p, evout.p, region_cap, tile_cnt.p, ctl.p, (R)(0.5 * skin_eff()),
-                         has_excl ? (const int*)excl_start.p : (const int*)nullptr, (const int*)excl_list.p, conn, (const unsigned int*)scan_role.p);
+                         has_excl ? (const int*)excl_start.p : (const int*)nullptr, (const int*)excl_list.p, conn, (const unsigned int*)scan_role.p, scan_roles_staged() ? 1 : 0);
       hipLaunchKernelGGL(k_cand_offsets, dim3(1), dim3(1024), 0, stream, ntiles, tile_cnt.p, tile_off.p, ctl.p);
       hipLaunchKernelGGL(k_cand_gather, dim3(std::min(ntiles, 2048)), dim3(256), 0, stream, ntiles, evout.p, region_cap, tile_cnt.p, tile_off.p, cdst, cand_cap, ctl.p);
     } else {

@@ -3095,7 +3095,7 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
                                                             const ReactSet* __restrict__ rs_g, Candidate* __restrict__ region, int region_cap,
                                                             int* __restrict__ tile_count, DevCtl* ctl, R slack,
                                                             const int* __restrict__ excl_start, const int* __restrict__ excl_list, ConnTable conn,
-                                                            const unsigned int* __restrict__ role) {
+                                                            const unsigned int* __restrict__ role, int roles_staged) {      // (roles_staged 0: the image leaves no room behind it -- role words from global memory)
   __shared__ TileLDS<R> T;
   __shared__ ReactSet rs;
   __shared__ int s_cnt;
@@ -3117,10 +3117,10 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
-    tile_fill_roles<R, BS>(T, sr, CAP, role);
+    if (roles_staged) tile_fill_roles<R, BS>(T, sr, CAP, role);
     __syncthreads();
     const int hx = T.geom[0], total = T.geom[3], nhome = T.geom[4];
-    if (threadIdx.x == 0 && total < CAP) sr[total] = 0u;      // (the far-away dummy slot: no role)
+    if (roles_staged && threadIdx.x == 0 && total < CAP) sr[total] = 0u;      // (the far-away dummy slot: no role)
     __syncthreads();
     Candidate* out = region + (size_t)tile * region_cap;
     for (int q = threadIdx.x; q < nhome; q += BS) {
@@ -3135,7 +3135,7 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
       int lx = 0;
       for (int k = 2; k <= hx; ++k) lx += (eh >= T.celloff[hr][k]) ? 1 : 0;
       const int sself = T.rowoff[hr] + eh;
-      const unsigned int rwi = sr[sself];
+      const unsigned int rwi = roles_staged ? sr[sself] : role[p];
       if (!rwi) continue;                                     // no role in any active reaction
       const Vec4<R> xi = sx[sself];
       const int tgi = tag[p];
@@ -3184,7 +3184,7 @@ __global__ __launch_bounds__(BS, 4) void k_react_scan_tiles(int ntiles, int CAP,
           const Vec4<R> xj = xq[u];
           const R dx = xi.x - xj.x, dy_ = xi.y - xj.y, dz_ = xi.z - xj.z;
           if (dx * dx + dy_ * dy_ + dz_ * dz_ > maxcut2 || sl == sself || sl >= b) continue;
-          const unsigned int rwj = sr[sl];
+          const unsigned int rwj = roles_staged ? sr[sl] : role[real_as_idx(xj.w) >> 5];
           const unsigned int fwdm = ri1 & (rwj >> 16), revm = ri2 & (rwj & 0xffffu);   // bit q: reaction q with (i, j) as roles (1, 2) / (2, 1)
           if (!(fwdm | revm)) continue;
           const int j = real_as_idx(xj.w) >> 5;

@@ -523,3 +523,24 @@ def test_decomposed_path_with_list_skin_and_inline_bonds(make_gpu, make_oracle, 
     fo2 = o2.get_state("FORCE")
     assert rel_err(c.get_state("FORCE"), fo2) < TOL[prec] and rel_err(d.get_state("FORCE"), fo2) < TOL[prec]
     assert c.observe()["epot_list"][0] == pytest.approx(o2.observe()["epot_list"][0], rel=1e-11 if prec == 64 else 1e-5)
+
+
+def test_reaction_scan_without_room_for_the_role_words(make_gpu, make_oracle):
+    """fp64, five crowded cells per axis: the 32-byte-per-slot image fills the LDS budget and leaves no room for the staged role
+    words of the reaction scan -- it reads them from global memory then (found by a randomised sweep: the decomposed path refused
+    this system outright while the role words counted towards the tile budget).  Events and bonds against the oracle, on the
+    slab path and on the single-domain path."""
+    spec = W.reactive_melt(n=4000, seed=12, interval=7)
+    spec["rebuild_criterion"] = 0
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e9
+    for dd in (1, 0):
+        g, o = make_gpu(64), make_oracle()
+        g.set_option("dd_self", dd)
+        h = W.apply(spec, g); W.apply(spec, o)
+        for _ in range(4):
+            g.run(7); o.run(7)
+        assert len(o.get_events()) > 1000
+        assert [e[:4] for e in sorted_events(g.get_events())] == [e[:4] for e in sorted_events(o.get_events())]
+        assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+        assert _tiles_in_use(g)[5] >= 4500                      # (the tile capacity that crowds the LDS)
