@@ -142,6 +142,7 @@ struct Ctx {
   int opt_fuse = 1;         // fused integrate2+integrate1
   int opt_lpt = 1;          // descriptors of the fused rebuild in largest-tile-first order per XCD range (force launch tail)
   int opt_dd_merge = 1;     // decomposed path: displacement fold in the integrate kernel, decision in the force kernel (no one-block launches)
+  bool opt_dd_fastx = true;  // decomposed path: excluded partners located as slots by the standalone list kernel (ghost copies through gtag)
   int opt_ablate_list = 0;  // diagnostics (with debug_stamps): parts of the list build left out, see tools/rebuild_stamps.py
   int opt_tiles = 1;        // LDS-tiled list/force kernels when the cell grid allows
   int opt_fused = 1;        // rebuild chain as one persistent launch with grid barriers (single domain, tiles)
@@ -308,6 +309,8 @@ template <typename R> struct CtxT : Ctx {
   int64_t dd_rebuilds = 0, dd_direct_rebuilds = 0;   // slab rebuilds: all of them / those the host called for itself (rebuild_now)
   int* hflag = nullptr; int* hflag_dev = nullptr; int hticket = 0;   // pinned decision word + ticket
   DBuf<double> dd_vals;
+  DBuf<int> gtag;                      // slab: index of a tag's ghost copy on this rank (-1: none)
+  DBuf<Box<R>> box_dev; Box<R> box_dev_host; bool box_dev_valid = false;   // device copy of the box for the standalone list kernel
   int S = 0;
   bool use_tiles = false, want32 = false;   // int32 list only built on demand (reaction steps, diagnostics)
   ActMask act{}; UniLJ uni{}; bool uniform_lj = false; bool all_active = false;
@@ -433,6 +436,9 @@ template <typename R> struct CtxT : Ctx {
     S = (ncap + 15) / 16 * 16;
     use_tiles = opt_tiles && box.nc[0] >= HX + 2 && box.nc[1] >= HY + 2 && (dd_on ? true : box.nc[2] >= HZ + 2);
     if (dd_on && !(box.nc[0] >= HX + 2 && box.nc[1] >= HY + 2)) throw ChemError(CHEM_EINVAL, "domain decomposition needs >= 5 cells along x and y");
+    // (the per-cell kernels know nothing of ghost layers: with tiles=0 a slab used to run on and return wrong forces -- found by
+    //  tests/test_gpu_sweep.py case 100)
+    if (dd_on && !use_tiles) throw ChemError(CHEM_EINVAL, "domain decomposition needs the LDS-staged tiles: option tiles=0 is a single-domain switch");
     if (use_tiles) {
       // LDS capacity from the mean stencil occupancy (+12 % for density fluctuations), in 256-slot steps
       const double per_cell = dd_on ? (double)nglob / ((double)box.nc[0] * box.nc[1] * nzg) : (double)n / box.ncell;
@@ -925,8 +931,20 @@ template <typename R> struct CtxT : Ctx {
       }
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c, (const int*)cell_sub.p);
       hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
+      // slabs: the excluded partners of a particle are located as slots like on the fused path (ghost copies through gtag) --
+      // without it every hit of a particle with exclusions paid a tag gather and a row scan (late stage: this launch 0.36 -> 1.59 ms)
+      const Box<R>* bxp = nullptr;
+      if (dd_on && has_excl && opt_dd_fastx && gtag.p) {
+        if (!box_dev.p) box_dev.alloc(1);
+        if (!box_dev_valid || std::memcmp(&box, &box_dev_host, sizeof(box)) != 0) {
+          std::memcpy(&box_dev_host, &box, sizeof(box)); box_dev_valid = true;
+          HIPCHK(hipMemcpyAsync(box_dev.p, &box_dev_host, sizeof(box), hipMemcpyHostToDevice, stream));
+        }
+        bxp = box_dev.p;
+      }
       hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), list_lds_need(want32), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
-                         excl_start.p, excl_list.p, has_excl, act, ntypes, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c, rl2_rows, bs);
+                         excl_start.p, excl_list.p, has_excl, act, ntypes, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c, rl2_rows, bs,
+                         bxp, (const int*)rtag.p, (const int*)gtag.p, G, G + n);
     } else if (box.nc[0] > 0)
       hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
                          excl_start.p, excl_list.p, has_excl, nlist.p, nn.p, S, c);
@@ -1048,10 +1066,37 @@ template <typename R> struct CtxT : Ctx {
                   Transport::Msg{tag.p + halo_dn_off, halo_dn_cnt * sizeof(int), tag.p + halo_up_off, halo_up_cnt * sizeof(int), tag.p + G + n, ngup * sizeof(int),
                                  tag.p + G - nglo, nglo * sizeof(int)}, lower, upper, stream);
     hipLaunchKernelGGL(k_ghost_cells, dim3(1), dim3(1024), 0, stream, nxy, ncz, gcnt_lo.p, gcnt_up.p, cell_start.p);
-    if (nglo) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(nglo, 256)), dim3(256), 0, stream, G - nglo, nglo, tag.p, rtag.p);
-    if (ngup) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(ngup, 256)), dim3(256), 0, stream, G + n, ngup, tag.p, rtag.p);
-    // 7. tiles + lists over the own layers
-    launch_list_chain();
+    if (gtag.n < (size_t)nglob) gtag.alloc(nglob);
+    hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nglob, 256)), dim3(256), 0, stream, gtag.p, -1, (size_t)nglob);
+    if (nglo) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(nglo, 256)), dim3(256), 0, stream, G - nglo, nglo, tag.p, rtag.p, gtag.p);
+    if (ngup) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(ngup, 256)), dim3(256), 0, stream, G + n, ngup, tag.p, rtag.p, gtag.p);
+    // 7. tiles + lists over the own layers.  A stencil beyond the LDS tile capacity or a row beyond its stride is a LOCAL matter
+    //    (both capacities are per rank, no collective depends on them): grow and build the lists again, here, instead of
+    //    carrying the flag to the end of the call and failing there (tests/test_gpu_sweep.py: a trimer melt at rho = 0.3
+    //    outgrew the capacity estimated from its first configuration in the middle of a run)
+    for (int attempt = 0; attempt < 4; ++attempt) {
+      launch_list_chain();
+      if (!use_tiles) break;
+      int ov[2];
+      collect_ints({&ctl.p->stage_overflow, &ctl.p->nl_overflow}, ov);
+      if (!ov[0] && !ov[1]) break;
+      if (ov[0]) {
+        const int want = (ov[0] + ov[0] / 8 + 255) / 256 * 256, old_cap = tile_cap;
+        if (want <= tile_cap) break;
+        tile_cap = want;
+        if (tile_lds_need() > kTileLdsBudget) { tile_cap = old_cap; break; }      // (stays flagged: reported by check_flags / rebuild_now)
+        set_tile_lds_attr();
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&ctl.p->stage_overflow, 0, 1, stream));
+        if (g_trace) fprintf(stderr, "[chem trace] slab rebuild: staged-tile capacity %d -> %d slots\n", old_cap, tile_cap);
+      }
+      if (ov[1]) {
+        if (nl_capacity_user > 0) break;
+        S = std::min(((int)(ov[1] * 1.25) + 31) / 16 * 16, std::max((nglob + 15) / 16 * 16, 16));
+        alloc_lists();
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&ctl.p->nl_overflow, 0, 1, stream));
+        if (g_trace) fprintf(stderr, "[chem trace] slab rebuild: list rows grown to %d entries\n", S);
+      }
+    }
     set_need_rebuild_async(0);
     if (g_trace) { HIPCHK(hipStreamSynchronize(stream)); trd.lap("ghosts+tiles+list"); }
     bwork_dirty = true;   // particle order and ghosts changed: the bonded work list is rebuilt before the next force evaluation
@@ -1090,6 +1135,7 @@ template <typename R> struct CtxT : Ctx {
       else { set_ctl_field(&DevCtl::force_rebuild, 1); decide_and_rebuild(); }
       DevCtl h = read_ctl();
       if (dd_on) agree_flags(h);
+      if (h.halt) set_ctl_field(&DevCtl::halt, 0);       // (a launch that could not finish its lists also stopped the run: this IS the recovery)
       if (h.mig_error) throw ChemError(CHEM_ESTATE, "domain decomposition: particle migration error " + std::to_string(h.mig_error));
       if (h.barrier_timeout) throw ChemError(CHEM_ESTATE, "fused rebuild: grid barrier timed out (device shared with another job?); set option fused_rebuild=0");
       if (h.bucket_overflow) {
@@ -1414,7 +1460,7 @@ template <typename R> struct CtxT : Ctx {
       set_ctl_field(&DevCtl::halt, 0);
       resort = true; resume = true; need_int1 = false;
       ++halts_recovered;
-      if (g_trace) fprintf(stderr, "[chem trace] run stopped by the device at step %lld (bucket rows of %d): recovering\n", (long long)h.halt_step, bcap);
+      if (g_trace) fprintf(stderr, "[chem trace] run stopped by the device at step %lld (bucket rows of %d, tile capacity %d, list rows of %d): recovering\n", (long long)h.halt_step, bcap, tile_cap, S);
       return true;
     };
     for (int64_t s = 0; s < nsteps; ++s) {
@@ -2583,6 +2629,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
   else if (k == "ablate_list") CTX.opt_ablate_list = (int)value;
   else if (k == "dd_merge") CTX.opt_dd_merge = value != 0;
+  else if (k == "dd_fastx") { CTX.opt_dd_fastx = value != 0; CTX.resort = true; }
   else if (k == "lpt_tiles") { CTX.opt_lpt = value != 0; CTX.resort = true; }
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }
   else if (k == "fused_rebuild") { CTX.opt_fused = value != 0; CTX.geom_dirty = true; }

@@ -778,11 +778,13 @@ __global__ __launch_bounds__(1024) void k_ghost_cells(int nxy, int own_layers, c
 }
 
 // rtag for ghost copies (only where the particle is not owned here)
-__global__ __launch_bounds__(256) void k_ghost_rtag(int g0, int ng, const int* __restrict__ tag, int* __restrict__ rtag) {
+// gtag: the ghost copy of every tag that has one here, owned or not (a one-rank slab holds a real particle AND its ghost)
+__global__ __launch_bounds__(256) void k_ghost_rtag(int g0, int ng, const int* __restrict__ tag, int* __restrict__ rtag, int* __restrict__ gtag) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= ng) return;
   const int t = tag[g0 + k];
   atomicCAS(&rtag[t], -1, g0 + k);
+  gtag[t] = g0 + k;
 }
 
 // =======================================================================================
@@ -1578,7 +1580,8 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
                                                    const int* excl_start, const int* excl_list, const int has_excl,
                                                    unsigned short* nl16, const int S16, int* nnh, int* nlist, const int S, int* nn, DevCtl* ctl,
                                                    const Box<RS>* bx, const int* rtag, const Vec4<RS>* x4, const int ablate = 0, const float rl2_rows_ = -1.f,
-                                                   uint4* bslots = nullptr) {
+                                                   uint4* bslots = nullptr, const int* gtag = nullptr, const int real0 = 0, const int real1 = 0x7fffffff) {
+  // (gtag, real0, real1: slab decomposition -- index of a tag's GHOST copy on this rank, range of the real particles)
   const float rl2_rows = rl2_rows_ > 0.f ? rl2_rows_ : rl2;   // int32 Verlet rows: the workload's rc+skin (the 16-bit force list may use a wider list skin)
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -1612,9 +1615,12 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
     if (has_excl && ablate != 5) { const int tg = tag[p]; e0 = excl_start[tg]; e1 = excl_start[tg + 1]; }      // (ablate 5, diagnostic: exclusions ignored)
     int cnt = 0, cnt16 = 0;
     int* row32 = nlist ? nlist + (size_t)p * S : nullptr;
-    // Exclusions without leaving the plain path (single domain): the few excluded partners of a particle are located
+    // Exclusions without leaving the plain path: the few excluded partners of a particle are located
     // in the staged tile ONCE (tag -> index -> position -> cell -> slot, the binning arithmetic repeated on the same
     // bits) and their bits are cleared from the hit masks, like the self pair.  More than 4 exclusions: generic path.
+    // On a slab (z-ghost mode) a partner across the slab boundary is a GHOST copy with its own index: rtag names the real
+    // particle where it is owned here, else the ghost; gtag names the ghost copy in any case (a one-rank slab holds both).
+    // The copy that counts is the one in a cell layer next to the home particle's (a partner is closer than one cell edge).
     int xs0 = -1, xs1 = -1, xs2 = -1, xs3 = -1;
     bool fastx = false;
     if (bx && e1 > e0 && e1 - e0 <= 4 && !row32) {
@@ -1625,14 +1631,25 @@ __device__ __forceinline__ void dev_nlist_tile_f32(const TileLDS<RS>& T, unsigne
       for (int k = 0; k < 4; ++k) {
         int slot = -1;
         if (e0 + k < e1) {
-          const int g = rtag[excl_list[e0 + k]];
-          if (g >= 0) {
+          const int tj = excl_list[e0 + k];
+          int g = rtag[tj];
+          for (int copy = 0; copy < 2 && slot < 0; ++copy) {      // (second trip: slabs only, the tag's ghost copy)
+            if (copy) { if (!gtag) break; const int g2 = gtag[tj]; if (g2 == g) break; g = g2; }
+            if (g < 0) continue;
             const Vec4<RS> xg = x4[g];
-            const int cx = pos_cell(xg.x, 0, nx, *bx), cy = pos_cell(xg.y, 1, ny, *bx), cz = pos_cell(xg.z, 2, nz, *bx);   // (the binning arithmetic on the same bits)
-            int kx = cx - (org & 1023) + 1, ky = cy - ((org >> 10) & 1023) + 1, kz = cz - (org >> 20) + 1;
+            const int cx = pos_cell(xg.x, 0, nx, *bx), cy = pos_cell(xg.y, 1, ny, *bx);   // (the binning arithmetic on the same bits)
+            int kx = cx - (org & 1023) + 1, ky = cy - ((org >> 10) & 1023) + 1, kz;
             kx += kx < 0 ? nx : 0; kx -= kx >= nx ? nx : 0;
             ky += ky < 0 ? ny : 0; ky -= ky >= ny ? ny : 0;
-            kz += kz < 0 ? nz : 0; kz -= kz >= nz ? nz : 0;
+            if (bx->zghost) {      // local layer: ghosts by their index range, reals by the binning arithmetic (dev_bin)
+              const int lzc = g < real0 ? 0 : (g >= real1 ? nz - 1 : pos_cell(xg.z, 2, bx->nzg, *bx) - bx->z0g + 1);
+              kz = lzc - (org >> 20) + 1;
+              const int dl = kz - (lz + 1);
+              if (kz < 0 || dl < -1 || dl > 1) continue;      // the far copy (or none here)
+            } else {
+              kz = pos_cell(xg.z, 2, nz, *bx) - (org >> 20) + 1;
+              kz += kz < 0 ? nz : 0; kz -= kz >= nz ? nz : 0;
+            }
             if (kx < hx + 2 && ky < T.geom[1] + 2 && kz < T.geom[2] + 2) {
               const int rr = kz * SY + ky, off = g - T.cellg[rr][kx];
               if (off >= 0 && off < T.celloff[rr][kx + 1] - T.celloff[rr][kx]) slot = T.rowoff[rr] + T.celloff[rr][kx] + off;
@@ -1812,10 +1829,14 @@ __global__ __launch_bounds__(BS, 4) void k_nlist_tiles(int ntiles, int CAP, cons
                                                     const TileLDS<R>* __restrict__ desc, R rl2,
                                                     const int* __restrict__ excl_start, const int* __restrict__ excl_list, int has_excl,
                                                     ActMask act, int ntypes, unsigned short* __restrict__ nl16, int S16, int* __restrict__ nnh,
-                                                    int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl, R rl2_rows, uint4* __restrict__ bslots) {
-  // (rl2: the radius the 16-bit force list is built for, rc + list skin; rl2_rows: the int32 Verlet rows', rc + skin)
+                                                    int* __restrict__ nlist, int S, int* __restrict__ nn, DevCtl* ctl, R rl2_rows, uint4* __restrict__ bslots,
+                                                    const Box<R>* __restrict__ boxp, const int* __restrict__ rtag, const int* __restrict__ gtag, int real0, int real1) {
+  // (rl2: the radius the 16-bit force list is built for, rc + list skin; rl2_rows: the int32 Verlet rows', rc + skin;
+  //  boxp/rtag/gtag/real0/real1: located-partner path of the exclusions on a slab, boxp == nullptr: generic path)
   if (!ctl->need_rebuild) return;
   __shared__ TileLDS<R> T;
+  __shared__ Box<R> sbox;
+  if (boxp) { const int* bs_ = reinterpret_cast<const int*>(boxp); int* bd_ = reinterpret_cast<int*>(&sbox); for (int k = threadIdx.x; k < (int)(sizeof(Box<R>) / 4); k += BS) bd_[k] = bs_[k]; }
   CHEM_DYN_LDS(R);
   for (int vb = blockIdx.x; vb < ntiles; vb += gridDim.x) {
     const int tile = xcd_remap(vb, ntiles);     // gridDim.x is a multiple of 8: vb % 8 == blockIdx.x % 8
@@ -1829,7 +1850,7 @@ __global__ __launch_bounds__(BS, 4) void k_nlist_tiles(int ntiles, int CAP, cons
       list_stage_f32<R, BS>(T, chem_dyn_lds, L, CAP, x4, act, ntypes);
       __syncthreads();
       dev_nlist_tile_f32<R, BS>(T, chem_dyn_lds, L, tag, (float)rl2, excl_start, excl_list, has_excl, nl16, S16, nnh, nlist, S, nn, ctl,
-                                (const Box<R>*)nullptr, nullptr, x4, 0, (float)rl2_rows, bslots);      // (bslots: inline bonds, see dev_nlist_tile_f32)
+                                boxp ? (const Box<R>*)&sbox : (const Box<R>*)nullptr, rtag, x4, 0, (float)rl2_rows, bslots, gtag, real0, real1);      // (bslots: inline bonds, see dev_nlist_tile_f32)
     } else {
       tile_fill<R, BS, true>(T, sx, CAP, x4, 1);
       __syncthreads();
@@ -2823,6 +2844,13 @@ __global__ __launch_bounds__(BS, CHEM_FUSED_WAVES) void k_rebuild_fused(const Fu
       a.x4[k] = xk; if (a.x0) a.x0[k] = xk;
       a.v4[k] = a.v4o[k]; a.img4[k] = a.img4o[k]; a.tag[k] = a.tago[k];
     }
+  }
+  // Lists this launch could not build -- a stencil beyond the LDS tile capacity, a row beyond its stride -- stop the run like a
+  // full bucket row does (the particles are sorted and consistent, the forces of this step never evaluated): the host grows
+  // the capacity at its next synchronisation and re-enters at this step (chem_api.hip: halted(), rebuild_now()).
+  if (t == 0) {
+    const volatile DevCtl* vc = ctl;
+    if (vc->stage_overflow | vc->nl_overflow) { ctl->halt_step = a.istep; ctl->halt = 1; }
   }
   if (b == 0 && t == 0) a.gb->stamp[6] = wall_clock64();
   if (wst) { __syncthreads(); if (t == 0) wst[7] |= (long long)(wall_clock64() - wst[0]) << 16; }

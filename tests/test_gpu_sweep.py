@@ -1,0 +1,240 @@
+"""Randomised sweep of the HIP path against the CPU oracle (seeded: every case is reproducible from its number).
+
+The hand-written parity tests sit on the BASELINE configurations; this one draws the things a user's system varies --
+size, density, box aspect, cutoff, skin, reaction cadence and rate -- together with the engine's own switches (slab
+path, fused rebuild, tiles, list skin, inline bonds, precision) and demands the same thing of every draw: the reaction
+event log and the bond list of the reference algorithm bit for bit (fp64), positions within rounding, forces within the
+suite's tolerances.  Reference semantics: integrator.run / ChemicalReaction as driven by start_simulation.py:728-796.
+"""
+import numpy as np
+import pytest
+
+from chemlab_amd import workloads as W
+from conftest import rel_err
+from helpers import force_error_without_cutoff_flips, sorted_events
+from test_gpu_parity import TOL
+
+pytestmark = pytest.mark.gpu
+
+SC = [k ** 3 for k in range(8, 27, 2)]          # simple-cubic sizes the reactive generator accepts (even k): 512 .. 17576
+FCC = [4 * k ** 3 for k in range(5, 17)]        # fcc sizes: 500 .. 16384
+
+
+def _stretch(spec, fac):
+    """The same lattice in an orthorhombic box (volume kept): positions and box scaled per axis."""
+    fac = np.asarray(fac, dtype=np.float64)
+    spec["pos"] = np.asarray(spec["pos"]) * fac
+    spec["box"] = (np.asarray(spec["box"]) * fac).tolist()
+    return spec
+
+
+BIG = [32 ** 3, 40 ** 3, 46 ** 3, 48 ** 3, 4 * 20 ** 3, 4 * 24 ** 3, 4 * 30 ** 3]      # 32k .. 110k: LDS tiles, automatic list skin
+
+
+def _draw_reactive(case, sizes=None):
+    rng = np.random.default_rng(1000 + case)
+    n = int(rng.choice(sizes or (SC + FCC)))
+    rc = float(rng.choice([2.0, 2.5, 3.0]))
+    skin = float(rng.uniform(0.15, 0.5))
+    rho = float(rng.uniform(0.45, 1.0))
+    interval = int(rng.integers(3, 13))
+    spec = W.reactive_melt(n=n, rho=rho, rc=rc, skin=skin, seed=200 + case, interval=interval,
+                           rcut_react=float(rng.uniform(1.0, min(1.6, rc))), jitter=float(rng.uniform(0.02, 0.12)))
+    a = float(rng.uniform(0.8, 1.25)); b = float(rng.uniform(0.8, 1.25))
+    if rng.random() < 0.6:
+        _stretch(spec, [a, b, 1.0 / (a * b)])
+    rate = 1e9 if rng.random() < 0.6 else float(rng.uniform(2.0, 40.0))      # finite rates: the keyed acceptance draw decides
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = rate
+    spec["rebuild_criterion"] = int(rng.integers(0, 2))
+    if rng.random() < 0.3:
+        spec["reaction"]["max_per_interval"] = int(rng.integers(5, 60))
+    if rng.random() < 0.3:
+        spec["thermal_types"] = [0, 2]
+    opts = {}
+    if rng.random() < 0.45:
+        opts["dd_self"] = 1
+    if rng.random() < 0.25:
+        opts["fused_rebuild"] = 0
+    if rng.random() < 0.15:
+        opts["tiles"] = 0
+    if rng.random() < 0.4:
+        opts["list_skin"] = skin + float(rng.uniform(0.0, 0.3))
+    if rng.random() < 0.25:
+        opts["bonds_inline"] = 0
+    elif rng.random() < 0.3:
+        opts["bond_pass"] = 0
+    prec = 64 if rng.random() < 0.7 else 32
+    return spec, opts, prec, interval
+
+
+def _apply_opts(g, opts):
+    for k in ("dd_self",):                         # (before anything else: it picks the transport)
+        if k in opts:
+            g.set_option(k, opts[k])
+    for k, v in opts.items():
+        if k != "dd_self":
+            g.set_option(k, v)
+
+
+@pytest.mark.parametrize("case", list(range(28)) + list(range(100, 108)))
+def test_random_reactive_system_matches_oracle(make_gpu, make_oracle, case):
+    """Cases 0-27: 500 .. 17k particles (3-10 cells per axis: every small-system path); 100-107: 32k .. 110k particles."""
+    spec, opts, prec, interval = _draw_reactive(case, BIG if case >= 100 else None)
+    g, o = make_gpu(prec), make_oracle()
+    _apply_opts(g, opts)
+    try:
+        h = W.apply(spec, g)
+        g.run(0)
+    except Exception as e:                         # a draw the engine refuses must be refused for a stated capacity reason
+        msg = str(e)
+        assert ("LDS" in msg or "capacity" in msg or "tiles" in msg or "cell" in msg), (case, opts, msg)
+        pytest.skip("case %d refused with a capacity message: %s" % (case, msg))
+    W.apply(spec, o)
+    o.run(0)
+    # forces of the initial configuration
+    fg, fo = g.get_state("FORCE"), o.get_state("FORCE")
+    if prec == 64:
+        assert rel_err(fg, fo) < TOL[64], (case, opts)
+    else:
+        err, flips = force_error_without_cutoff_flips(spec, fg, fo, 2e-5, max_flips=8)
+        assert err < 2e-5 and 0 <= flips <= 8, (case, opts, err, flips)
+    og, oo = g.observe(), o.observe()
+    assert og["epot_lj"] == pytest.approx(oo["epot_lj"], rel=1e-10 if prec == 64 else 2e-5)
+    for _ in range(4):
+        g.run(interval); o.run(interval)
+    eg, eo = sorted_events(g.get_events()), sorted_events(o.get_events())
+    if prec == 64:
+        assert [e[:4] for e in eg] == [e[:4] for e in eo], (case, opts)
+        assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"])), (case, opts)
+        assert np.array_equal(g.get_state("STATE"), o.get_state("STATE")) and np.array_equal(g.get_state("TYPE"), o.get_state("TYPE"))
+        assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8, (case, opts)
+        assert rel_err(g.get_state("VEL"), o.get_state("VEL")) < 1e-6, (case, opts)
+        if "list_skin" not in opts:
+            tg, to = g.timers(), o.timers()
+            assert to["rebuilds"] <= tg["rebuilds"] <= to["rebuilds"] + 4, (case, opts, tg["rebuilds"], to["rebuilds"])
+    else:
+        # fp32 trajectories part from the fp64 one at rounding level; a candidate whose distance sits on the reaction radius may
+        # fall to the other side: the logs agree but for a handful of events
+        sg, so = set(e[:4] for e in eg), set(e[:4] for e in eo)
+        assert len(sg ^ so) <= max(4, len(so) // 100), (case, opts, len(sg ^ so), len(so))
+        assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 2e-4, (case, opts)
+
+
+def _draw_polymer(case):
+    rng = np.random.default_rng(5000 + case)
+    nch = int(rng.integers(40, 400)); ln = int(rng.integers(6, 33))
+    spec = W.polymer_melt(n_chains=nch, chain_len=ln, rho=float(rng.uniform(2.5, 4.0)), seed=300 + case,
+                          skin=float(rng.uniform(0.08, 0.25)))
+    a = float(rng.uniform(0.85, 1.2)); b = float(rng.uniform(0.85, 1.2))
+    if rng.random() < 0.5:
+        _stretch(spec, [a, b, 1.0 / (a * b)])
+    opts = {}
+    if rng.random() < 0.4:
+        opts["dd_self"] = 1
+    if rng.random() < 0.25:
+        opts["fused_rebuild"] = 0
+    if rng.random() < 0.15:
+        opts["tiles"] = 0
+    return spec, opts, (64 if rng.random() < 0.6 else 32)
+
+
+@pytest.mark.parametrize("case", range(10))
+def test_random_polymer_melt_matches_oracle(make_gpu, make_oracle, case):
+    """Tabulated pairs + stiff harmonic bonds + angles + nrexcl-3 exclusions (mf/espp_cg_1 shape) at random sizes."""
+    spec, opts, prec = _draw_polymer(case)
+    g, o = make_gpu(prec), make_oracle()
+    _apply_opts(g, opts)
+    try:
+        W.apply(spec, g)
+        g.run(0)
+    except Exception as e:
+        msg = str(e)
+        assert ("LDS" in msg or "capacity" in msg or "tiles" in msg or "cell" in msg), (case, opts, msg)
+        pytest.skip("case %d refused with a capacity message: %s" % (case, msg))
+    W.apply(spec, o)
+    o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < (TOL[64] if prec == 64 else 5e-5), (case, opts)
+    og, oo = g.observe(), o.observe()
+    assert og["epot_tab"] == pytest.approx(oo["epot_tab"], rel=1e-10 if prec == 64 else 2e-5)
+    for k in range(2):
+        assert og["epot_list"][k] == pytest.approx(oo["epot_list"][k], rel=1e-10 if prec == 64 else 5e-4)
+    assert np.array_equal(g.get_exclusions(), o.get_exclusions())
+    g.run(30); o.run(30)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-8 if prec == 64 else 2e-4), (case, opts)
+    if prec == 64:
+        assert g.timers()["rebuilds"] == o.timers()["rebuilds"], (case, opts)
+
+
+def _draw_trimer(case):
+    rng = np.random.default_rng(9000 + case)
+    spec = W.trimer_melt(n_mol=int(rng.integers(150, 6000)), rho=float(rng.uniform(0.2, 0.5)), seed=400 + case,
+                         skin=float(rng.uniform(0.2, 0.5)), interval=int(rng.integers(5, 25)))
+    spec["rebuild_criterion"] = int(rng.integers(0, 2))
+    opts = {}
+    if rng.random() < 0.45:
+        opts["dd_self"] = 1
+    if rng.random() < 0.25:
+        opts["fused_rebuild"] = 0
+    return spec, opts
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_trimer_melt_topology_matches_oracle(make_gpu, make_oracle, case):
+    """examples/atrp_lj shape at random sizes and densities: end-group coupling, the topology manager spawning angles for the
+    registered type triples, exclusions growing with every bond, cluster labels merged -- all lists bit for bit (fp64)."""
+    spec, opts = _draw_trimer(case)
+    g, o = make_gpu(64), make_oracle()
+    _apply_opts(g, opts)
+    try:
+        h = W.apply(spec, g)
+        g.run(0)
+    except Exception as e:
+        msg = str(e)
+        assert ("LDS" in msg or "capacity" in msg or "tiles" in msg or "cell" in msg), (case, opts, msg)
+        pytest.skip("case %d refused with a capacity message: %s" % (case, msg))
+    W.apply(spec, o)
+    iv = spec["reaction"]["interval"]
+    for _ in range(3):
+        g.run(iv); o.run(iv)
+    assert [e[:4] for e in sorted_events(g.get_events())] == [e[:4] for e in sorted_events(o.get_events())], (case, opts)
+    for k in (0, 1, "reaction_bonds"):
+        assert np.array_equal(g.get_list(h[k]), o.get_list(h[k])), (case, opts, k)
+    assert np.array_equal(g.get_exclusions(), o.get_exclusions())
+    assert np.array_equal(g.get_state("RESID"), o.get_state("RESID"))
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8, (case, opts)
+    og, oo = g.observe(), o.observe()
+    assert np.allclose(og["epot_list"], oo["epot_list"], rtol=1e-8) and og["list_size"] == oo["list_size"]
+
+
+def _debug(g):
+    """(tile capacity in slots, runs the device stopped and the host resumed)"""
+    import ctypes
+    out = (ctypes.c_int32 * 6)()
+    g.api.lib.chem_debug_tiles.restype = ctypes.c_int64
+    g.api.lib.chem_debug_halts.restype = ctypes.c_int64
+    assert g.api.lib.chem_debug_tiles(ctypes.c_void_p(g.ctx), out) == 0
+    return int(out[5]), int(g.api.lib.chem_debug_halts(ctypes.c_void_p(g.ctx)))
+
+
+@pytest.mark.parametrize("dd", [0, 1])
+def test_tile_capacity_outgrown_in_the_middle_of_a_run(make_gpu, make_oracle, dd):
+    """Draw 1 of the trimer sweep (4737 beads at rho = 0.3, lattice start): the LDS tile capacity is estimated from the mean cell
+    occupancy, and this melt clusters beyond it some tens of steps into a run.  Both paths used to carry the flag to the end of
+    the call and fail there; now the slab rebuild grows the capacity on the spot and the fused single-domain launch stops the
+    run at that step (DevCtl::halt), the host grows the capacity and re-enters -- the trajectory is the oracle's either way."""
+    spec, _ = _draw_trimer(1)
+    g, o = make_gpu(64), make_oracle()
+    if dd:
+        g.set_option("dd_self", 1)
+    h = W.apply(spec, g); W.apply(spec, o)
+    g.run(0); o.run(0)
+    cap0 = _debug(g)[0]
+    iv = spec["reaction"]["interval"]
+    for k in range(3):
+        g.run(iv); o.run(iv)
+    cap1, halts = _debug(g)
+    assert cap1 > cap0 and (dd or halts >= 1), (cap0, cap1, halts)               # it did happen
+    assert [e[:4] for e in sorted_events(g.get_events())] == [e[:4] for e in sorted_events(o.get_events())]
+    assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
