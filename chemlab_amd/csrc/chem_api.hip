@@ -260,7 +260,8 @@ template <typename R> struct CtxT : Ctx {
   bool opt_bond_pass = true;
   void set_bond_pass(bool v) override { opt_bond_pass = v; }
   DBuf<BondRec<R>> brec_dev; BondRec<R> brec_host{}; bool brec_valid = false;
-  bool bond_by_pass() { return opt_bond_pass && use_fused && !dd_on && bonds_inline() && excl_over == 0; }
+  bool bond_by_pass() { return opt_bond_pass && ((use_fused && !dd_on) || (dd_on && use_tiles && opt_dd_fastx)) && bonds_inline() && excl_over == 0; }
+  bool dd_record_bonds = false;      // slabs, bond pass: the next force launch records the partner slots (set by the slab rebuild)
   bool bonds_inline() {
     if (!opt_bonds_inline || !(use_fused || (dd_on && use_tiles)) || nbent <= 0 || !harmonic_only || !bonds_excluded) return false;
     // the exclusion set must BE the bond set (bonds are a subset: bonds_excluded; both are duplicate-free): equal counts
@@ -924,17 +925,21 @@ template <typename R> struct CtxT : Ctx {
     DevCtl* c = ctl.p;
     const R rl2 = (R)((rc + skin_eff()) * (rc + skin_eff())), rl2_rows = (R)((rc + skin) * (rc + skin));   // (they differ on the tile path only)
     if (use_tiles) {
-      uint4* bs = nullptr;      // inline bonds (decomposed path: the standalone list kernel records the partner slots)
+      uint4* bs = nullptr;      // inline bonds (decomposed path: the standalone list kernel records the partner slots ...)
+      int list_excl = has_excl;
       if (dd_on && bonds_inline()) {
         if (bslots.n < 2 * (size_t)acap()) bslots.alloc(2 * (size_t)acap() + 1024);
         bs = bslots.p;
+        // (... unless the bond pass is on: the list build ignores the exclusions = bonds, the force launch behind this rebuild
+        //  records the partner slots and every force launch takes the partners' pair term out again, as on the fused path)
+        if (bond_by_pass() && !want32) { bs = nullptr; list_excl = 0; dd_record_bonds = true; }
       }
       hipLaunchKernelGGL((k_tile_desc<R>), dim3(std::min(ntiles, 2048)), dim3(128), 0, stream, ntiles, tile_cap, cell_start.p, box, tdesc.p, c, (const int*)cell_sub.p);
       hipLaunchKernelGGL((k_tile_scan<R>), dim3(1), dim3(1024), 0, stream, ntiles, tdesc.p, c);
       // slabs: the excluded partners of a particle are located as slots like on the fused path (ghost copies through gtag) --
       // without it every hit of a particle with exclusions paid a tag gather and a row scan (late stage: this launch 0.36 -> 1.59 ms)
       const Box<R>* bxp = nullptr;
-      if (dd_on && has_excl && opt_dd_fastx && gtag.p) {
+      if (dd_on && has_excl && opt_dd_fastx && gtag.p && !(bond_by_pass() && !want32)) {
         if (!box_dev.p) box_dev.alloc(1);
         if (!box_dev_valid || std::memcmp(&box, &box_dev_host, sizeof(box)) != 0) {
           std::memcpy(&box_dev_host, &box, sizeof(box)); box_dev_valid = true;
@@ -943,7 +948,7 @@ template <typename R> struct CtxT : Ctx {
         bxp = box_dev.p;
       }
       hipLaunchKernelGGL((k_nlist_tiles<R, 512>), dim3(ntiles), dim3(512), list_lds_need(want32), stream, ntiles, tile_cap, x4.p, tag.p, tdesc.p, rl2,
-                         excl_start.p, excl_list.p, has_excl, act, ntypes, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c, rl2_rows, bs,
+                         excl_start.p, excl_list.p, list_excl, act, ntypes, nl16.p, S, nnh.p, want32 ? nlist.p : (int*)nullptr, S, nn.p, c, rl2_rows, bs,
                          bxp, (const int*)rtag.p, (const int*)gtag.p, G, G + n);
     } else if (box.nc[0] > 0)
       hipLaunchKernelGGL((k_nlist_cells<R, 1536>), dim3(std::min(box.ncell, 2560)), dim3(256), 0, stream, n, x4.p, tag.p, cell_start.p, box, rl2,
@@ -1206,12 +1211,17 @@ template <typename R> struct CtxT : Ctx {
   template <bool ENERGY> int launch_pair(V4* fdst, int tpp) {
     const double hs = 0.5 * skin_eff();
     const bool inline_now = bonds_inline();
-    const int bond_mode = inline_now ? (bond_by_pass() ? 2 : 1) : 0;      // (what the LAST rebuild did: both only change where a rebuild is forced)
+    int bond_mode = inline_now ? (bond_by_pass() ? 2 : 1) : 0;      // (what the LAST rebuild did: both only change where a rebuild is forced)
+    if (bond_mode == 2 && dd_on) {      // slabs: the host knows which launch follows a rebuild (mode 3 = mode 2 + record the partner slots now)
+      if (dd_record_bonds) bond_mode = 3;
+      if (pair_subset != 1) dd_record_bonds = false;      // (a launch of the interior tiles alone is followed by the boundary launch of the same step)
+    }
     const BondRec<R>* brec = nullptr;
-    if (bond_mode == 2) {      // device copy of what the force launch behind a rebuild needs to record the partner slots (refreshed when a pointer or the box changed)
+    if (bond_mode >= 2) {      // device copy of what the force launch behind a rebuild needs to record the partner slots (refreshed when a pointer or the box changed)
       BondRec<R> now;
       std::memset(&now, 0, sizeof(now));      // (compared bytewise below: no indeterminate padding)
       now.tag = tag.p; now.excl_start = excl_start.p; now.excl_list = excl_list.p; now.rtag = rtag.p;
+      now.gtag = dd_on ? gtag.p : nullptr; now.real0 = dd_on ? G : 0; now.real1 = dd_on ? G + n : 0x7fffffff;
       std::memcpy(&now.box, &box, sizeof(box));
       if (!brec_dev.p) brec_dev.alloc(1);
       if (!brec_valid || std::memcmp(&now, &brec_host, sizeof(now)) != 0) {
@@ -1230,7 +1240,7 @@ template <typename R> struct CtxT : Ctx {
       if (nsub <= 0) return 0;
 #define LTD(T, M, B, D) hipLaunchKernelGGL((k_pair_tiles<R, T, ENERGY, B, M, D>), dim3(nsub), dim3(B), pair_lds_bytes(), stream, nsub, tile_cap, x4.p, fdst, tdesc.p, \
                                  nl16.p, nnh.p, S, pcore.p, pext.p, ntypes, tab.p, uni, eout.p, hs, ctl.p, pair_guard, opt_ablate, dbg_on ? dbgbuf.p : (long long*)nullptr, ts, pair_da, \
-                                 (inline_now && (!ENERGY || bond_mode == 2)) ? bslots.p : (uint4*)nullptr, inline_K, inline_r0, bond_mode, act, brec)
+                                 (inline_now && (!ENERGY || bond_mode >= 2)) ? bslots.p : (uint4*)nullptr, inline_K, inline_r0, bond_mode, act, brec)
 #define LT(T, M, B) LTD(T, M, B, false)
       // diagnostics (options debug_stamps / ablate): one instantiation, one lane per particle, 512 threads
 #define LTB(T, M) do { if ((dbg_on || opt_ablate) && !ENERGY) { if (T != 1 || pair_bs != 512) throw ChemError(CHEM_EINVAL, "debug_stamps / ablate need tpp=1 and pair_block=512"); LTD(1, M, 512, true); } \

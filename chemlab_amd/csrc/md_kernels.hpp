@@ -1931,13 +1931,24 @@ struct TileSub { int base1, n1, base2; };
 // halo exchange and the forces.  The accumulated distance is double-buffered by step parity (read [par], written [par^1]).
 // LDS slot of particle g (sorted index, position xg) in the staged image of the tile described by T; -1: outside its stencil.
 // (cell of g by the binning arithmetic on the same bits, relative to the tile's first home cell with the periodic wrap)
+// Slabs (bx.zghost): the local layer of a ghost follows from its index range (below real0: lower ghost layer, from real1 on:
+// upper), that of a real particle from the binning arithmetic; hz = stencil row (z) of the home particle -- only a copy in a
+// layer next to it counts (a one-rank slab holds a particle and its ghost, possibly both inside one stencil).
 template <typename R>
-__device__ __forceinline__ int tile_partner_slot(const TileLDS<R>& T, int g, const Vec4<R>& xg, const Box<R>& bx, DevCtl* ctl) {
+__device__ __forceinline__ int tile_partner_slot(const TileLDS<R>& T, int g, const Vec4<R>& xg, const Box<R>& bx, DevCtl* ctl,
+                                                 const int real0 = 0, const int real1 = 0x7fffffff, const int hz = 0) {
   const int nx = bx.nc[0], ny = bx.nc[1], nz = bx.nc[2], org = T.geom[6];
-  int kx = pos_cell(xg.x, 0, nx, bx) - (org & 1023) + 1, ky = pos_cell(xg.y, 1, ny, bx) - ((org >> 10) & 1023) + 1, kz = pos_cell(xg.z, 2, nz, bx) - (org >> 20) + 1;
+  int kx = pos_cell(xg.x, 0, nx, bx) - (org & 1023) + 1, ky = pos_cell(xg.y, 1, ny, bx) - ((org >> 10) & 1023) + 1, kz;
   kx += kx < 0 ? nx : 0; kx -= kx >= nx ? nx : 0;
   ky += ky < 0 ? ny : 0; ky -= ky >= ny ? ny : 0;
-  kz += kz < 0 ? nz : 0; kz -= kz >= nz ? nz : 0;
+  if (bx.zghost) {
+    const int lzc = g < real0 ? 0 : (g >= real1 ? nz - 1 : pos_cell(xg.z, 2, bx.nzg, bx) - bx.z0g + 1);
+    kz = lzc - (org >> 20) + 1;
+    if (kz < 0 || kz - hz < -1 || kz - hz > 1) return -1;
+  } else {
+    kz = pos_cell(xg.z, 2, nz, bx) - (org >> 20) + 1;
+    kz += kz < 0 ? nz : 0; kz -= kz >= nz ? nz : 0;
+  }
   if (kx < T.geom[0] + 2 && ky < T.geom[1] + 2 && kz < T.geom[2] + 2) {
     const int rr = kz * SY + ky, off = g - T.cellg[rr][kx];
     if (off >= 0 && off < T.celloff[rr][kx + 1] - T.celloff[rr][kx]) return T.rowoff[rr] + T.celloff[rr][kx] + off;
@@ -1946,7 +1957,7 @@ __device__ __forceinline__ int tile_partner_slot(const TileLDS<R>& T, int g, con
   return -1;
 }
 // what the force kernel needs to record the bonded partners' slots itself (bond_mode 2, launch of a rebuild step)
-template <typename R> struct BondRec { const int *tag, *excl_start, *excl_list, *rtag; Box<R> box; };
+template <typename R> struct BondRec { const int *tag, *excl_start, *excl_list, *rtag, *gtag; int real0, real1; Box<R> box; };   // (gtag, real0, real1: slabs)
 // The force launch behind a rebuild records, for home particle p of the tile described by *T, the LDS slots of its bonded
 // (= excluded) partners: tag -> exclusion row -> partner index -> partner position -> cell -> slot through the tile tables;
 // written out for the launches up to the next rebuild, first quad returned.  A real function call on purpose: inlined, its
@@ -1963,12 +1974,22 @@ __device__ __noinline__ uint4 bond_record(const TileLDS<R>* T, int p, const Bond
   for (int k = 0; k < kBondSlots; ++k) w[k] = ~0u;
   const int tg = brec.tag[p];
   const int e0 = brec.excl_start[tg], e1 = brec.excl_start[tg + 1];
+  int hz = 0;      // stencil row (z) of the home particle: from the home run that holds p
+  if (brec.box.zghost) {
+#pragma unroll 1
+    for (int k = 0; k < NHSEG; ++k) if (p >= T->hstart[k] && p < T->hstart[k] + (T->hoff[k + 1] - T->hoff[k])) hz = k / HY + 1;
+  }
   if (e1 > e0 && e1 - e0 <= kBondSlots) {
 #pragma unroll
     for (int k = 0; k < kBondSlots; ++k) {
       if (e0 + k >= e1) break;
-      const int g = brec.rtag[brec.excl_list[e0 + k]];
-      const int sl = g >= 0 ? tile_partner_slot<R>(*T, g, x4[g], brec.box, ctl) : -1;
+      const int tj = brec.excl_list[e0 + k];
+      const int g = brec.rtag[tj];
+      int sl = g >= 0 ? tile_partner_slot<R>(*T, g, x4[g], brec.box, ctl, brec.real0, brec.real1, hz) : -1;
+      if (sl < 0 && brec.gtag) {      // slabs: the tag's ghost copy
+        const int g2 = brec.gtag[tj];
+        if (g2 >= 0 && g2 != g) sl = tile_partner_slot<R>(*T, g2, x4[g2], brec.box, ctl, brec.real0, brec.real1, hz);
+      }
       if (sl < 0) ctl->bond_slot_miss = 1;      // every bonded partner sits inside the stencil (bond length << cell edge)
       else w[k] = (unsigned int)sl;
     }
@@ -2050,7 +2071,9 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
   int p = -1, cnt = 0, hslot = 0, qq = 0;
   uint4 pkv[NCH];
   uint4 bwv = make_uint4(~0u, ~0u, ~0u, ~0u);
-  const bool bond_rec = bslots && brec && bond_mode == 2 && ctl->need_rebuild != 0;      // (uniform: set by the rebuild of THIS step, cleared by the next idle decision)
+  // (uniform.  Single domain: set by the rebuild of THIS step, cleared by the next idle decision; slabs: the host rebuilds, it
+  //  asks for the record with bond_mode 3 = mode 2 + record now)
+  const bool bond_rec = bslots && brec && ((bond_mode == 2 && ctl->need_rebuild != 0) || bond_mode == 3);
   auto locate = [&](int q) {
     int sgi = 0;
 #pragma unroll
@@ -2188,7 +2211,7 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
             if constexpr (D3) { xj = lds_gather3d(sx, sl); xj.w = (R)d3_types<R>(sx, CAP)[sl]; } else xj = sx[sl];
             const R dx = xi.x - xj.x, dy = xi.y - xj.y, dz = xi.z - xj.z;
             const R r2 = dx * dx + dy * dy + dz * dz;
-            if (bond_mode == 2) {
+            if (bond_mode >= 2) {
               if (MODE == 2 && !ENERGY) {
                 if (r2 <= u_rc2 && ((bact.row[(int)xi.w & 15] >> ((int)xj.w & 15)) & 1u)) {
                   const R r2i = rcp_r(r2), r6i = r2i * r2i * r2i;
