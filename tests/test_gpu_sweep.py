@@ -238,3 +238,41 @@ def test_tile_capacity_outgrown_in_the_middle_of_a_run(make_gpu, make_oracle, dd
     assert [e[:4] for e in sorted_events(g.get_events())] == [e[:4] for e in sorted_events(o.get_events())]
     assert np.array_equal(g.get_list(h["reaction_bonds"]), o.get_list(h["reaction_bonds"]))
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+
+
+@pytest.mark.parametrize("P,bond_pass", [(3, 1), (4, 1), (4, 0)])
+def test_reactive_slabs_with_three_and_four_ranks(make_gpu, make_oracle, P, bond_pass):
+    """Three and four slabs as threads of this process (distinct lower and upper neighbours; two ranks are covered by
+    test_dd_multi_rank_in_process_reactive): reaction bonds across slab boundaries -- the bonded partner of a home particle is
+    then a GHOST copy, located through the ghost tag map by the list build (bond_pass 0) or by the force launch behind a slab
+    rebuild (bond_pass 1).  Events, bonds, states and the trajectory of the single-domain oracle."""
+    from test_gpu_parity import _HUB, _run_ranks
+    spec = W.reactive_melt(n=16384, seed=77, interval=10)
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e9
+    o = make_oracle()
+    ho = W.apply(spec, o)
+    for _ in range(5):
+        o.run(10)
+    engs = [make_gpu(64) for _ in range(P)]
+    _HUB[0] += 1
+    hub = _HUB[0]
+
+    def rank(r):
+        g = engs[r]
+        g.comm_init_local(P, r, hub)
+        g.set_option("bond_pass", bond_pass)
+        h = W.apply(spec, g)
+        for _ in range(5):
+            g.run(10)
+        return dict(ev=sorted_events(g.get_events()), bonds=g.get_list(h["reaction_bonds"]), st=g.get_state("STATE"),
+                    x=g.get_state("POS_UNFOLDED"), el=g.observe()["epot_list"])
+    out = _run_ranks(P, rank)
+    eo = sorted_events(o.get_events())
+    assert len(eo) > 3000
+    for r in range(P):
+        assert [e[:4] for e in out[r]["ev"]] == [e[:4] for e in eo]
+        assert np.array_equal(out[r]["bonds"], o.get_list(ho["reaction_bonds"]))
+        assert np.array_equal(out[r]["st"], o.get_state("STATE"))
+        assert rel_err(out[r]["x"], o.get_state("POS_UNFOLDED")) < 1e-8
+        assert np.allclose(out[r]["el"], o.observe()["epot_list"], rtol=1e-9)
