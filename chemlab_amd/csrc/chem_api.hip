@@ -2474,7 +2474,6 @@ int chem_reaction_neighbour_change(chem_ctx* ctx, const chem_nb_change* r) {
   REQUIRE(r->invoke_on >= 1 && r->invoke_on <= 3 && r->nb_level >= 1, CHEM_EINVAL, "neighbour_change: invoke_on must be 1, 2 or 3 and nb_level >= 1");
   REQUIRE(r->old_type >= 0 && r->old_type < CHEM_MAX_TYPES && r->new_type >= 0 && r->new_type < CHEM_MAX_TYPES, CHEM_EINVAL, "neighbour_change: types");
   REQUIRE(r->new_mass > 0, CHEM_EINVAL, "neighbour_change: new_mass");
-  REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "neighbour property changes on the decomposed path");
   c.nb_rules.push_back(*r); c.pair_dirty = true;
   return 0;
   API_END(ctx)
@@ -2485,7 +2484,6 @@ int chem_reaction_constraint(chem_ctx* ctx, int reaction, int role, int nb_type,
   Ctx& c = CTX;
   REQUIRE(reaction >= 0 && reaction < (int)c.reactions.size() && reaction < 32, CHEM_EINVAL, "reaction_constraint: reaction index");
   REQUIRE((role == 1 || role == 2) && nb_type >= 0 && nb_type < CHEM_MAX_TYPES, CHEM_EINVAL, "reaction_constraint: role must be 1 or 2, nb_type a type id");
-  REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "reaction constraints on the decomposed path");
   if (c.constraints.size() < c.reactions.size()) c.constraints.resize(c.reactions.size());
   c.constraints[reaction] = Ctx::NbCons{role, nb_type, min_state, max_state};
   return 0;
@@ -2497,7 +2495,6 @@ int chem_reaction_restrict(chem_ctx* ctx, int reaction, int64_t n, const int64_t
   Ctx& c = CTX;
   REQUIRE(reaction >= 0 && reaction < (int)c.reactions.size() && reaction < 32, CHEM_EINVAL, "reaction_restrict: reaction index");
   REQUIRE(n >= 0 && (n == 0 || p), CHEM_EINVAL, "reaction_restrict: pairs");
-  REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "restricted reactions on the decomposed path");
   for (int64_t k = 0; k < n; ++k) {
     const int a = c.top.tag_of(p[2 * k]), b = c.top.tag_of(p[2 * k + 1]);
     REQUIRE(a >= 0 && b >= 0 && a != b, CHEM_EINVAL, "reaction_restrict: unknown id or self pair");
@@ -2514,7 +2511,6 @@ int chem_atrp_init(chem_ctx* ctx, const chem_atrp_desc* d) {
   if (!d) { c.atrp_on = false; return 0; }
   REQUIRE(d->interval > 0 && d->num_particles > 0, CHEM_EINVAL, "atrp_init: interval and num_particles must be positive");
   REQUIRE(d->ratio_activator >= 0 && d->ratio_deactivator >= 0 && d->delta_catalyst >= 0 && d->k_activate >= 0 && d->k_deactivate >= 0, CHEM_EINVAL, "atrp_init: negative rate or ratio");
-  REQUIRE(!c.dd_on, CHEM_ENOTIMPL, "ATRPActivator on the decomposed path");
   c.atrp = *d; c.atrp_on = true;
   return 0;
   API_END(ctx)

@@ -69,10 +69,11 @@ def _draw_reactive(case, sizes=None):
 
 
 def _refused(e, case, opts=None):
-    """A draw the engine refuses must be refused for a stated reason: a capacity / geometry limit, or a feature the decomposed
-    path declares unimplemented (CHEM_ENOTIMPL: ATRPActivator and reaction constraints on slabs)."""
+    """A draw the engine refuses must be refused for a stated reason: a capacity / geometry limit of the slab decomposition
+    or of the LDS tiles.  (Until the sweep's second widening the decomposed path also refused ATRPActivator, reaction
+    constraints, restricted reactions and neighbour property changes -- lifted, see test_reaction_extensions_on_slabs.)"""
     msg = str(e)
-    assert ("LDS" in msg or "capacity" in msg or "tiles" in msg or "cell" in msg or "on the decomposed path" in msg), (case, opts, msg)
+    assert ("LDS" in msg or "capacity" in msg or "tiles" in msg or "cell" in msg), (case, opts, msg)
     pytest.skip("case %s refused: %s" % (case, msg))
 
 
@@ -395,3 +396,119 @@ def test_random_exchange_reaction_matches_oracle(make_gpu, make_oracle, case):
     assert len(eo) > 50 and [e[:4] for e in eg] == [e[:4] for e in eo], case
     assert np.array_equal(g.get_state("TYPE"), o.get_state("TYPE")) and np.array_equal(g.get_state("STATE"), o.get_state("STATE"))
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < 1e-8
+
+
+def _ranks_or_self(make_gpu, P, setup, run):
+    """`setup(g)` then `run(g)` on P slabs: P == 1 through dd_self, P > 1 as threads of this process.  Returns run()'s results."""
+    from test_gpu_parity import _HUB, _run_ranks
+    if P == 1:
+        g = make_gpu(64)
+        g.set_option("dd_self", 1)
+        setup(g)
+        return [run(g)]
+    engs = [make_gpu(64) for _ in range(P)]
+    _HUB[0] += 1
+    hub = _HUB[0]
+
+    def rank(r):
+        engs[r].comm_init_local(P, r, hub)
+        setup(engs[r])
+        return run(engs[r])
+    return _run_ranks(P, rank)
+
+
+@pytest.mark.parametrize("P", [1, 3])
+def test_reaction_extensions_on_slabs(make_gpu, make_oracle, P):
+    """The reaction extensions the decomposed path used to refuse (CHEM_ENOTIMPL until round 3): ATRPActivator, restricted
+    reactions (connectivity map), neighbour-state constraints with neighbour property changes (exchange reactions) and
+    PostProcessChangeNeighboursProperty through the topology manager.  The host side of each is replicated on every rank
+    and the by-tag device arrays are too, so every rank takes the same decisions; types written by tag reach the ghost copies
+    with the next halo update.  One slab (dd_self) and three slabs (threads), each against the single-domain oracle."""
+    from test_oracle_extensions import _apply_exchange, _exchange_spec
+    # -- ATRPActivator beside the chain-growth reactions
+    spec = W.reactive_melt(n=13824, seed=43, interval=20)
+    spec["state"] = np.where(spec["types"] == 0, 0, 1).astype(np.int32)
+    spec["atrp"] = dict(interval=10, num_particles=1500, ratio_activator=0.5, ratio_deactivator=0.5, delta_catalyst=0.3,
+                        k_activate=1.0, k_deactivate=0.6, select_from_all=True, seed=17,
+                        centers=[dict(type_id=0, state=0, is_activator=False, new_type=0, new_mass=1.0, delta_state=1),
+                                 dict(type_id=0, state=3, is_activator=True, new_type=0, new_mass=1.0, delta_state=-3)])
+    o = make_oracle()
+    ho = W.apply(spec, o)
+    for _ in range(4):
+        o.run(25)
+    hh = {}
+
+    def run_atrp(g):
+        for _ in range(4):
+            g.run(25)
+        return dict(stats=g.atrp_stats(), ev=[e[:4] for e in sorted_events(g.get_events())], st=g.get_state("STATE"), ty=g.get_state("TYPE"),
+                    bonds=g.get_list(hh["h"]["reaction_bonds"]), x=g.get_state("POS_UNFOLDED"))
+    for res in _ranks_or_self(make_gpu, P, lambda g: hh.__setitem__("h", W.apply(spec, g)), run_atrp):
+        assert res["stats"] == o.atrp_stats() and sum(r["activated"] for r in res["stats"]) > 200
+        assert res["ev"] == [e[:4] for e in sorted_events(o.get_events())] and len(res["ev"]) > 50
+        assert np.array_equal(res["st"], o.get_state("STATE")) and np.array_equal(res["ty"], o.get_state("TYPE"))
+        assert np.array_equal(res["bonds"], o.get_list(ho["reaction_bonds"]))
+        assert rel_err(res["x"], o.get_state("POS_UNFOLDED")) < 1e-8
+    # -- exchange reaction: constraint + neighbour property change
+    spec = _exchange_spec(n_mol=3000, seed=35)
+    spec["rebuild_criterion"] = 1
+    o = make_oracle()
+    _apply_exchange(spec, o)
+    for _ in range(3):
+        o.run(5)
+
+    def run_ex(g):
+        for _ in range(3):
+            g.run(5)
+        return dict(ev=[e[:4] for e in sorted_events(g.get_events())], st=g.get_state("STATE"), ty=g.get_state("TYPE"), x=g.get_state("POS_UNFOLDED"))
+    for res in _ranks_or_self(make_gpu, P, lambda g: _apply_exchange(spec, g), run_ex):
+        assert res["ev"] == [e[:4] for e in sorted_events(o.get_events())] and len(res["ev"]) > 100
+        assert np.array_equal(res["st"], o.get_state("STATE")) and np.array_equal(res["ty"], o.get_state("TYPE"))
+        assert rel_err(res["x"], o.get_state("POS_UNFOLDED")) < 1e-8
+    # -- restricted reaction (connectivity map)
+    spec = W.reactive_melt(n=8788, seed=61, interval=10)
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e9
+    probe = make_oracle()
+    W.apply(spec, probe)
+    probe.run(30)
+    ev = probe.get_events()
+    allowed = np.stack([ev["id_a"], ev["id_b"]], 1)[ev["reaction"] == 1][::2]
+    assert len(allowed) > 50
+    o = make_oracle()
+    ho = W.apply(spec, o)
+    o.reaction_restrict(1, allowed)
+    o.run(30)
+
+    def setup_rs(g):
+        hh["h"] = W.apply(spec, g)
+        g.reaction_restrict(1, allowed)
+
+    def run_rs(g):
+        g.run(30)
+        return dict(ev=[e[:4] for e in sorted_events(g.get_events())], st=g.get_state("STATE"), bonds=g.get_list(hh["h"]["reaction_bonds"]))
+    for res in _ranks_or_self(make_gpu, P, setup_rs, run_rs):
+        assert res["ev"] == [e[:4] for e in sorted_events(o.get_events())] and len(res["ev"]) > 100
+        assert np.array_equal(res["st"], o.get_state("STATE")) and np.array_equal(res["bonds"], o.get_list(ho["reaction_bonds"]))
+    # -- PostProcessChangeNeighboursProperty through the topology manager (atrp_lj shape)
+    spec = W.trimer_melt(n_mol=1728, seed=6, interval=20)
+    MA, ML, PA, PL = 0, 1, 2, 3
+    spec["lj"] += [(PA, t, 1.0, 1.0, spec["rc"]) for t in (MA, ML, PA)] + [(PL, t, 1.0, 1.0, spec["rc"]) for t in (MA, ML, PA, PL)]
+
+    def setup_nb(e):
+        W.apply(spec, e)
+        e.reaction_neighbour_change(0, "both", ML, 1, PL, 1.5, new_state=1)
+        e.reaction_neighbour_change(0, "both", MA, 2, PA, 2.0)
+    o = make_oracle()
+    setup_nb(o)
+    o.run(60)
+
+    def run_nb(g):
+        g.run(60)
+        return dict(ev=[e[:4] for e in sorted_events(g.get_events())], st=g.get_state("STATE"), ty=g.get_state("TYPE"), m=g.get_state("MASS"),
+                    x=g.get_state("POS_UNFOLDED"))
+    for res in _ranks_or_self(make_gpu, P, setup_nb, run_nb):
+        assert res["ev"] == [e[:4] for e in sorted_events(o.get_events())] and len(res["ev"]) > 10
+        assert np.array_equal(res["ty"], o.get_state("TYPE")) and (res["ty"] == PL).sum() > 0 and (res["ty"] == PA).sum() > 0
+        assert np.array_equal(res["st"], o.get_state("STATE")) and np.allclose(res["m"], o.get_state("MASS"))
+        assert rel_err(res["x"], o.get_state("POS_UNFOLDED")) < 1e-8
