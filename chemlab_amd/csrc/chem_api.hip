@@ -141,6 +141,7 @@ struct Ctx {
   int64_t pair_launch_no = 0;
   int opt_fuse = 1;         // fused integrate2+integrate1
   int opt_lpt = 1;          // descriptors of the fused rebuild in largest-tile-first order per XCD range (force launch tail)
+  bool opt_dd_fold = true;   // decomposed path: block maxima folded by atomics of the integrate kernel (no fold launch per step)
   int opt_dd_merge = 1;     // decomposed path: displacement fold in the integrate kernel, decision in the force kernel (no one-block launches)
   bool opt_dd_fastx = true;  // decomposed path: excluded partners located as slots by the standalone list kernel (ghost copies through gtag)
   int opt_ablate_list = 0;  // diagnostics (with debug_stamps): parts of the list build left out, see tools/rebuild_stamps.py
@@ -310,6 +311,9 @@ template <typename R> struct CtxT : Ctx {
   int64_t dd_rebuilds = 0, dd_direct_rebuilds = 0;   // slab rebuilds: all of them / those the host called for itself (rebuild_now)
   int* hflag = nullptr; int* hflag_dev = nullptr; int hticket = 0;   // pinned decision word + ticket
   DBuf<double> dd_vals;
+  DBuf<unsigned long long> foldmax;    // decomposed path: atomic fold of the step's displacement maxima (kFoldSlots words, md_kernels.hpp)
+  bool fold_on() const { return dd_merged() && opt_dd_fold; }
+  unsigned long long* fold_arg() { return (dd_on && fold_on()) ? foldmax.p : nullptr; }
   DBuf<int> gtag;                      // slab: index of a tag's ghost copy on this rank (-1: none)
   DBuf<Box<R>> box_dev; Box<R> box_dev_host; bool box_dev_valid = false;   // device copy of the box for the standalone list kernel
   int S = 0;
@@ -981,7 +985,9 @@ template <typename R> struct CtxT : Ctx {
     HIPCHK(hipHostMalloc((void**)&hflag, 4096, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(hflag, 0, 4096);
     HIPCHK(hipHostGetDevicePointer((void**)&hflag_dev, hflag, 0));
-    dd_vals.alloc(64);
+    dd_vals.alloc(64 * kFoldSlots);
+    foldmax.alloc(kFoldSlots);
+    HIPCHK(hipMemsetAsync(foldmax.p, 0, kFoldSlots * sizeof(unsigned long long), stream));
   }
   void poll_ticket(volatile int* word, int ticket, const char* what) {
     long long spins = 0;
@@ -1310,11 +1316,11 @@ template <typename R> struct CtxT : Ctx {
     // consumes exactly that; without a thermostat f4 is never overwritten, so every launch does.
     const R cap = (cap_force > 0 && (with_lang || !lang)) ? (R)cap_force : (R)0;
     if (with_lang && storef)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, true>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p, fold_arg());
     else if (with_lang)
-      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, true, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p, fold_arg());
     else
-      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p);
+      hipLaunchKernelGGL((k_integrate<R, MODE, false, false>), dim3(nb), dim3(256), 0, stream, n, x4.p + G, v4.p + G, f4.p + G, tag.p + G, (R)dt, lp, blockmax.p, opt_criterion ? x0.p + G : (const V4*)nullptr, cap, pos_scale(), (const DevCtl*)ctl.p, fold_arg());
   }
 
   void check_flags() {
@@ -1352,12 +1358,19 @@ template <typename R> struct CtxT : Ctx {
   void dd_step_sync() {
     ensure_hflag();
     if (dd_merged()) {
-      hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), kIntPerBlock), 0.5 * skin_eff(), opt_criterion, 1,
-                         (const double*)nullptr, 0, (volatile int*)nullptr, 0, 0.5 * skin);
-      tr->exchange_with_scalar(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
-                               x4.p + G - nglo, nglo * sizeof(V4), lower, upper, &ctl.p->step_m2, dd_vals.p, stream);
+      const bool fold = fold_on();
+      if (fold) {
+        // the integrate kernel has folded the block maxima into foldmax with atomics: the words travel with the halo, no fold launch
+        tr->exchange_with_scalar(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
+                                 x4.p + G - nglo, nglo * sizeof(V4), lower, upper, reinterpret_cast<const double*>(foldmax.p), dd_vals.p, stream, kFoldSlots);
+      } else {
+        hipLaunchKernelGGL(k_rebuild_decide<R>, dim3(1), dim3(1024), 0, stream, ctl.p, blockmax.p, cdiv(acap(), kIntPerBlock), 0.5 * skin_eff(), opt_criterion, 1,
+                           (const double*)nullptr, 0, (volatile int*)nullptr, 0, 0.5 * skin);
+        tr->exchange_with_scalar(x4.p + halo_dn_off, halo_dn_cnt * sizeof(V4), x4.p + halo_up_off, halo_up_cnt * sizeof(V4), x4.p + G + n, ngup * sizeof(V4),
+                                 x4.p + G - nglo, nglo * sizeof(V4), lower, upper, &ctl.p->step_m2, dd_vals.p, stream);
+      }
       const int ticket = ++hticket;
-      pair_da = DecideArgs{dd_vals.p, P, (volatile int*)hflag_dev, ticket, dd_par, opt_criterion, 0.5 * skin};
+      pair_da = DecideArgs{dd_vals.p, P, (volatile int*)hflag_dev, ticket, dd_par, opt_criterion, 0.5 * skin, fold ? foldmax.p : nullptr};
       dd_par ^= 1;
       compute_forces(true, 0);     // (guard 2: decision in the prologue of the force kernel)
       pair_da = DecideArgs{};
@@ -2635,6 +2648,7 @@ int chem_set_option(chem_ctx* ctx, const char* name, double value) {
   else if (k == "fuse_integrate") CTX.opt_fuse = value != 0;
   else if (k == "ablate_list") CTX.opt_ablate_list = (int)value;
   else if (k == "dd_merge") CTX.opt_dd_merge = value != 0;
+  else if (k == "dd_fold") CTX.opt_dd_fold = value != 0;
   else if (k == "dd_fastx") { CTX.opt_dd_fastx = value != 0; CTX.resort = true; }
   else if (k == "lpt_tiles") { CTX.opt_lpt = value != 0; CTX.resort = true; }
   else if (k == "tiles") { CTX.opt_tiles = value != 0; CTX.geom_dirty = true; }

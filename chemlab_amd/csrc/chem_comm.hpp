@@ -52,7 +52,8 @@ struct Transport {
   // slot [rank] of every other rank's `all` array (the step's displacement maximum: the list-rebuild
   // decision needs the global max, and a separate all-reduce would cost a second launch + latency).
   virtual void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
-                                    void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) = 0;
+                                    void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s, int count = 1) = 0;
+  // (count: 8-byte words per rank -- slot [rank * count .. ) of `all`)
   virtual void allreduce_max_f64(double* dev, size_t count, hipStream_t s) = 0;
   virtual void allreduce_sum_f64(double* dev, size_t count, hipStream_t s) = 0;
   // out must hold nranks*bytes; in may alias out + rank*bytes
@@ -68,9 +69,9 @@ struct SelfTransport : Transport {
     if (up_bytes && hipMemcpyAsync(from_lo, up, up_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) throw ChemError(CHEM_ECOMM, "self copy");
   }
   void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
-                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) override {
+                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s, int count = 1) override {
     exchange(dn, dn_bytes, up, up_bytes, from_up, from_up_bytes, from_lo, from_lo_bytes, lower, upper, s);
-    (void)hipMemcpyAsync(all, my, sizeof(double), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(all, my, sizeof(double) * count, hipMemcpyDeviceToDevice, s);
   }
   void allreduce_max_f64(double*, size_t, hipStream_t) override {}
   void allreduce_sum_f64(double*, size_t, hipStream_t) override {}
@@ -154,7 +155,7 @@ struct RcclTransport : Transport {
     ck(a.GroupEnd(), "ncclGroupEnd");
   }
   void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
-                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) override {
+                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s, int count = 1) override {
     RcclApi& a = rccl_api();
     ck(a.GroupStart(), "ncclGroupStart");
     ck(a.Send(dn, dn_bytes, RcclApi::kInt8, lower, comm, s), "ncclSend");
@@ -162,8 +163,8 @@ struct RcclTransport : Transport {
     ck(a.Recv(from_up, from_up_bytes, RcclApi::kInt8, upper, comm, s), "ncclRecv");
     ck(a.Recv(from_lo, from_lo_bytes, RcclApi::kInt8, lower, comm, s), "ncclRecv");
     for (int r = 0; r < nranks; ++r) {   // 8-byte all-to-all riding in the same group (one launch, one latency)
-      ck(a.Send(my, sizeof(double), RcclApi::kInt8, r, comm, s), "ncclSend");
-      ck(a.Recv(all + r, sizeof(double), RcclApi::kInt8, r, comm, s), "ncclRecv");
+      ck(a.Send(my, sizeof(double) * count, RcclApi::kInt8, r, comm, s), "ncclSend");
+      ck(a.Recv(all + (size_t)r * count, sizeof(double) * count, RcclApi::kInt8, r, comm, s), "ncclRecv");
     }
     ck(a.GroupEnd(), "ncclGroupEnd");
   }
@@ -225,9 +226,9 @@ struct LocalTransport : Transport {
     hub->barrier();
   }
   void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
-                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) override {
+                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s, int count = 1) override {
     exchange(dn, dn_bytes, up, up_bytes, from_up, from_up_bytes, from_lo, from_lo_bytes, lower, upper, s);
-    allgather(my, all, sizeof(double), s);
+    allgather(my, all, sizeof(double) * count, s);
   }
   void allreduce(double* dev, size_t count, hipStream_t s, bool is_max) {
     std::vector<double> v(count);
@@ -337,16 +338,18 @@ struct IpcTransport : Transport {
     barrier();
   }
   void exchange_with_scalar(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes,
-                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s) override {
+                            void* from_lo, size_t from_lo_bytes, int lower, int upper, const double* my, double* all, hipStream_t s, int count = 1) override {
     exchange(dn, dn_bytes, up, up_bytes, from_up, from_up_bytes, from_lo, from_lo_bytes, lower, upper, s);
-    double v = 0;
-    ck(hipMemcpyAsync(&v, my, sizeof(double), hipMemcpyDeviceToHost, s), "copy"); ck(hipStreamSynchronize(s), "sync");
-    shm->red[rank][0] = v;
-    barrier();
-    double a[IpcShm::kMaxRanks];
-    for (int q = 0; q < nranks; ++q) a[q] = shm->red[q][0];
-    ck(hipMemcpyAsync(all, a, sizeof(double) * nranks, hipMemcpyHostToDevice, s), "copy"); ck(hipStreamSynchronize(s), "sync");
-    barrier();
+    if (count == 1) {
+      double v = 0;
+      ck(hipMemcpyAsync(&v, my, sizeof(double), hipMemcpyDeviceToHost, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+      shm->red[rank][0] = v;
+      barrier();
+      double a[IpcShm::kMaxRanks];
+      for (int q = 0; q < nranks; ++q) a[q] = shm->red[q][0];
+      ck(hipMemcpyAsync(all, a, sizeof(double) * nranks, hipMemcpyHostToDevice, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+      barrier();
+    } else allgather(my, all, sizeof(double) * count, s);
   }
   void allreduce(double* dev, size_t count, hipStream_t s, bool is_max) {
     if (count > 64) throw ChemError(CHEM_ECOMM, "ipc transport: reduction of more than 64 values");

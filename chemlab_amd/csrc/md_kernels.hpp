@@ -200,6 +200,7 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 // =======================================================================================
 // K7/K8  velocity-Verlet halves (start_simulation.py:165-167,780)
 // =======================================================================================
+constexpr int kFoldSlots = 64;   // words of the atomic displacement fold of the decomposed path (k_integrate, k_pair_tiles guard 2)
 template <typename R> struct LangevinP { int on; double kT, gamma, dt; uint64_t seed; uint64_t step; uint32_t phase;
   uint32_t tmask; };   // thermal groups (LangevinThermostat.add_valid_types, start_simulation.py:312-336): bit t set = type t is thermalised; 0 = every type
 
@@ -224,7 +225,11 @@ template <typename R, int MODE, bool LANG, bool STOREF>
 __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ x4, Vec4<R>* __restrict__ v4,
                                                     Vec4<R>* __restrict__ f4, const int* __restrict__ tag,
                                                     R dt, LangevinP<R> lp, unsigned long long* __restrict__ blockmax,
-                                                    const Vec4<R>* __restrict__ x0, R cap, PosScale<R> ps, const DevCtl* __restrict__ ctl) {
+                                                    const Vec4<R>* __restrict__ x0, R cap, PosScale<R> ps, const DevCtl* __restrict__ ctl,
+                                                    unsigned long long* __restrict__ foldmax = nullptr) {
+  // foldmax (decomposed path): kFoldSlots words that collect the block maxima with one atomicMax per block (block b -> word
+  // b % kFoldSlots: a few dozen atomics per address, spread over the launch) -- the one-block fold launch between this kernel
+  // and the halo exchange is gone; the words travel with the halo, the force kernel's prologue takes the maximum and clears them
   if (ctl->halt) return;   // (uniform scalar load; see DevCtl::halt)
   // kIntPerBlock particles per 256-thread block: every thread owns kIntPerBlock/256 particles and issues
   // all their loads before the first dependent instruction (more bytes in flight per wave for this
@@ -286,6 +291,7 @@ __global__ __launch_bounds__(256) void k_integrate(int n, Vec4<R>* __restrict__ 
       unsigned long long m = wm[0];
       for (int k = 1; k < 4; ++k) m = wm[k] > m ? wm[k] : m;
       blockmax[blockIdx.x] = m;
+      if (foldmax) atomicMax(&foldmax[blockIdx.x % kFoldSlots], m);
     }
   }
 }
@@ -2000,7 +2006,9 @@ __device__ __noinline__ uint4 bond_record(const TileLDS<R>* T, int p, const Bond
   return q0;
 }
 
-struct DecideArgs { const double* gathered; int n; volatile int* host_flag; int ticket, par, criterion; double half_skin_ref; };
+// (fold != nullptr: `gathered` holds n * kFoldSlots bit patterns of squared displacements -- every rank's fold words, see
+//  k_integrate -- instead of n doubles; `fold` = this rank's words, cleared here for the next step)
+struct DecideArgs { const double* gathered; int n; volatile int* host_flag; int ticket, par, criterion; double half_skin_ref; unsigned long long* fold; };
 
 // (fp64: the 32-byte-per-slot image allows one or two workgroups per CU anyway -- 128 registers instead of 80 and spills)
 // DIAG = true: diagnostic instantiation with per-block phase stamps (`dbg`) and early exits (`ablate`: 1 stop after
@@ -2025,8 +2033,18 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
   if (DIAG && dbg) st0 = wall_clock64();
   if (DIAG && ablate == 4) return;   // diagnostic: dispatch cost only
   if (guard == 2) {
-    double m2 = da.gathered[0];
-    for (int q = 1; q < da.n; ++q) m2 = da.gathered[q] > m2 ? da.gathered[q] : m2;
+    double m2;
+    if (da.fold) {      // every wave for itself: lane l takes words l, l + 64, ... of all ranks, then a wave maximum
+      const unsigned long long* gw = reinterpret_cast<const unsigned long long*>(da.gathered);
+      unsigned long long mb = 0;
+      for (int q = lane_id(); q < da.n * kFoldSlots; q += 64) { const unsigned long long v = gw[q]; mb = v > mb ? v : mb; }
+      for (int o = 32; o > 0; o >>= 1) { const unsigned long long v = __shfl_xor(mb, o); mb = v > mb ? v : mb; }
+      m2 = sizeof(R) == 4 ? bits_real_f(mb) : bits_real_d(mb);
+      if (blockIdx.x == 0 && threadIdx.x < kFoldSlots) da.fold[threadIdx.x] = 0ull;      // (sent already: the exchange is ahead of this launch in the stream)
+    } else {
+      m2 = da.gathered[0];
+      for (int q = 1; q < da.n; ++q) m2 = da.gathered[q] > m2 ? da.gathered[q] : m2;
+    }
     const double acc = da.criterion ? sqrt(m2) : ctl->acc_pp[da.par] + sqrt(m2);
     const int forced = ctl->force_rebuild;
     const int need = (acc > half_skin) || forced;
@@ -2074,6 +2092,9 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
   // (uniform.  Single domain: set by the rebuild of THIS step, cleared by the next idle decision; slabs: the host rebuilds, it
   //  asks for the record with bond_mode 3 = mode 2 + record now)
   const bool bond_rec = bslots && brec && ((bond_mode == 2 && ctl->need_rebuild != 0) || bond_mode == 3);
+#ifndef CHEM_NT_PRE
+#define CHEM_NT_PRE 1
+#endif
   auto locate = [&](int q) {
     int sgi = 0;
 #pragma unroll
@@ -2086,7 +2107,7 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
     if (bslots && !bond_rec) bwv = bslots[2 * (size_t)p];   // (inline bonds: first quad, issued with the list chunks, consumed after the pair loop)
 #pragma unroll
     for (int c = 0; c < NCH; ++c)                           // the tile's region is always allocated: safe before cnt is known
-      pkv[c] = (sub + c * TPP) * 8 < S16 ? nt_load_u4(&reg[(size_t)(sub + c * TPP) * nhome + q]) : make_uint4(0, 0, 0, 0);
+      pkv[c] = (sub + c * TPP) * 8 < S16 ? (CHEM_NT_PRE ? nt_load_u4(&reg[(size_t)(sub + c * TPP) * nhome + q]) : reg[(size_t)(sub + c * TPP) * nhome + q]) : make_uint4(0, 0, 0, 0);
   };
   if (slice < nhome) locate(slice);
   constexpr bool D3 = sizeof(R) == 8;     // fp64: 24-byte slots + type bytes (see tile_fill)
@@ -2179,12 +2200,15 @@ __global__ __launch_bounds__(BS, sizeof(R) == 8 ? 4 : (BS == 1024 ? 2048 : 1536)
         int c = sub + NCH * TPP;
         bool have = c * 8 < cnt;
         uint4 cur = make_uint4(0, 0, 0, 0);
-        if (have) cur = reg[(size_t)c * nhome + qq];
+#ifndef CHEM_NT_TAIL
+#define CHEM_NT_TAIL 0
+#endif
+        if (have) cur = CHEM_NT_TAIL ? nt_load_u4(&reg[(size_t)c * nhome + qq]) : reg[(size_t)c * nhome + qq];
         while (have) {
           const int cn = c + TPP;
           const bool hn = cn * 8 < cnt;
           uint4 nx = make_uint4(0, 0, 0, 0);
-          if (hn) nx = reg[(size_t)cn * nhome + qq];
+          if (hn) nx = CHEM_NT_TAIL ? nt_load_u4(&reg[(size_t)cn * nhome + qq]) : reg[(size_t)cn * nhome + qq];
           do_chunk(cur);
           cur = nx; have = hn; c = cn;
         }
