@@ -101,7 +101,8 @@ class MyArgParser(argparse.ArgumentParser):
         return [t if t.startswith("--") else "--" + t]
 
     def save_to_file(self, output_file, namespace):
-        with open(output_file, "w") as f:
+        from ..rank import wopen
+        with wopen(output_file, "w") as f:
             for k, v in sorted(vars(namespace).items()):
                 if v is not None:
                     f.write("%s=%s\n" % (k, v))

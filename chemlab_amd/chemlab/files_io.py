@@ -200,5 +200,6 @@ def read_exclusion_list(file_name):
 
 
 def write_exclusion_list(file_name, exclusions):
-    with open(file_name, "w") as f:
+    from ..rank import wopen
+    with wopen(file_name, "w") as f:
         f.write("\n".join("%d %d" % tuple(d) for d in sorted(exclusions)))

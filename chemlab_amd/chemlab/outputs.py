@@ -10,6 +10,7 @@ this image does not have: trajectories are out of scope, the end state is not.
 The three `TopologyManager.save_*` files are written by ESPResSo++ itself in the reference (C++ side, not under
 /root/reference): the layout used here -- one `key: members...` row per entry, ascending -- is this build's own
 [EXT-RECALL]."""
+from ..rank import wopen
 import collections
 import os
 
@@ -17,7 +18,7 @@ import os
 def _prepare_path(file_name):
     d = os.path.dirname(file_name)
     if d and not os.path.isdir(d):
-        os.makedirs(d)
+        os.makedirs(d, exist_ok=True)      # (several ranks may arrive here together)
     return file_name
 
 
@@ -36,7 +37,7 @@ def write_gro(file_name, conf, positions, box, velocities=None, title=None):
             out.append("%5d%-5s%5s%5d%8.3f%8.3f%8.3f%8.3f%8.3f%8.3f" % (at.chain_idx, at.chain_name, at.name, at.atom_id,
                                                                          p[0], p[1], p[2], v[0], v[1], v[2]))
     out.append("%f %f %f\n" % tuple(box))
-    with open(_prepare_path(file_name), "w") as f:
+    with wopen(_prepare_path(file_name), "w") as f:
         f.write("\n".join(out))
 
 
@@ -105,7 +106,7 @@ def tuple_rows(kind, static_lists, dynamic_lists, chem_fpls, atoms, gt):
 
 
 def write_rows(file_name, rows):
-    with open(_prepare_path(file_name), "w") as f:
+    with wopen(_prepare_path(file_name), "w") as f:
         for r in rows:
             f.write("%s\n" % " ".join(str(x) for x in r))
 
@@ -150,7 +151,7 @@ def write_output_topology(file_name, gt, atoms, bonds, angles, dihedrals):
     section("pairs", [])
     section("system", [t.system_name or "system"])
     section("molecules", ["MOL 1"])
-    with open(_prepare_path(file_name), "w") as f:
+    with wopen(_prepare_path(file_name), "w") as f:
         f.writelines(sec)
 
 
@@ -169,7 +170,7 @@ def write_topology_dumps(prefix, system, fixed_pair_lists):
     ids, res = eng.get_state("ID").tolist(), eng.get_state("RESID").tolist()
     res_of = dict(zip(ids, res))
     adj = bond_graph(fixed_pair_lists)
-    with open(_prepare_path(prefix + "_topology.dat"), "w") as f:            # particle: bonded partners
+    with wopen(_prepare_path(prefix + "_topology.dat"), "w") as f:            # particle: bonded partners
         for pid in sorted(adj):
             f.write("%d: %s\n" % (pid, " ".join(str(x) for x in sorted(adj[pid]))))
     radj = collections.defaultdict(set)
@@ -177,12 +178,12 @@ def write_topology_dumps(prefix, system, fixed_pair_lists):
         for b in adj[a]:
             if res_of[a] != res_of[b]:
                 radj[res_of[a]].add(res_of[b])
-    with open(_prepare_path(prefix + "_res_topology.dat"), "w") as f:        # residue: residues it is bonded to
+    with wopen(_prepare_path(prefix + "_res_topology.dat"), "w") as f:        # residue: residues it is bonded to
         for r in sorted(radj):
             f.write("%d: %s\n" % (r, " ".join(str(x) for x in sorted(radj[r]))))
     members = collections.defaultdict(list)
     for pid, r in zip(ids, res):
         members[r].append(pid)
-    with open(_prepare_path(prefix + "_residue_list.dat"), "w") as f:        # residue: its particles
+    with wopen(_prepare_path(prefix + "_residue_list.dat"), "w") as f:        # residue: its particles
         for r in sorted(members):
             f.write("%d: %s\n" % (r, " ".join(str(x) for x in sorted(members[r]))))

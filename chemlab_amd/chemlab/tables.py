@@ -45,6 +45,10 @@ def convert_table(gro_in, espp_out, sigma=1.0, epsilon=1.0, c6=1.0, c12=1.0):
             f_ = c6 * c[4] + c12 * c[6]
         r, e, f_ = r / sigma, e / epsilon, f_ * sigma / epsilon
         out.append("%15.8g %15.8g %15.8g\n" % (r, e, f_))
-    with open(espp_out, "w") as f:
+    # written under a private name and renamed: with several ranks converting the same table at once (multi-process runs:
+    # every rank sets the interactions up) a reader never sees half a file, and all writers produce the same bytes
+    tmp = "%s.tmp%d" % (espp_out, os.getpid())
+    with open(tmp, "w") as f:
         f.writelines(out)
+    os.replace(tmp, espp_out)
     return len(out)

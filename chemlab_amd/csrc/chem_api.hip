@@ -1988,7 +1988,10 @@ template <typename R> struct CtxT : Ctx {
     for (int v : cnts) { mx = std::max<size_t>(mx, v); tot += v; }
     std::vector<unsigned char> all(tot * rec);
     if (mx == 0) return all;
-    gbuf.alloc(mx * rec * P);
+    // sized once for any record type and a slab 50 % over its share (it only grows beyond that): the inter-process transport
+    // maps peer allocations by handle and caches the mappings -- a buffer that is freed and allocated again at another size
+    // between two gathers handed the peers a stale mapping ("copy: invalid argument" in the multi-process driver run)
+    if (gbuf.n < mx * rec * P) gbuf.alloc(std::max(mx * rec * P, ((size_t)nglob * 3 / (2 * (size_t)P) + 1024) * 64 * (size_t)P));
     if (nloc) HIPCHK(hipMemcpyAsync(gbuf.p + (size_t)rk * mx * rec, loc.data(), loc.size(), hipMemcpyHostToDevice, stream));
     tr->allgather(gbuf.p + (size_t)rk * mx * rec, gbuf.p, mx * rec, stream);
     std::vector<unsigned char> raw(mx * rec * P);

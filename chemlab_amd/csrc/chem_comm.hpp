@@ -325,7 +325,14 @@ struct IpcTransport : Transport {
     if (shm->post[q].bytes[k] != bytes) throw ChemError(CHEM_ECOMM, "ipc transport: message size mismatch");
     if (!bytes) return;
     const void* src = q == rank ? own_src : peer_ptr(q, k);
-    ck(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s), "copy");
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) {
+      hipDeviceptr_t db = nullptr; size_t dsz = 0;
+      (void)hipMemGetAddressRange(&db, &dsz, (hipDeviceptr_t)dst);
+      throw ChemError(CHEM_ECOMM, std::string("ipc transport: copy from rank ") + std::to_string(q) + " slot " + std::to_string(k) + ": " + hipGetErrorString(e) + " (" +
+                      std::to_string(bytes) + " bytes at peer offset " + std::to_string((unsigned long long)shm->post[q].off[k]) + ", destination offset " +
+                      std::to_string((size_t)((const char*)dst - (const char*)db)) + " of " + std::to_string(dsz) + ", mappings cached " + std::to_string(opened.size()) + ")");
+    }
   }
   void exchange(const void* dn, size_t dn_bytes, const void* up, size_t up_bytes, void* from_up, size_t from_up_bytes, void* from_lo,
                 size_t from_lo_bytes, int lower, int upper, hipStream_t s) override {
@@ -342,19 +349,19 @@ struct IpcTransport : Transport {
     exchange(dn, dn_bytes, up, up_bytes, from_up, from_up_bytes, from_lo, from_lo_bytes, lower, upper, s);
     if (count == 1) {
       double v = 0;
-      ck(hipMemcpyAsync(&v, my, sizeof(double), hipMemcpyDeviceToHost, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+      ck(hipMemcpyAsync(&v, my, sizeof(double), hipMemcpyDeviceToHost, s), "scalar to host"); ck(hipStreamSynchronize(s), "sync");
       shm->red[rank][0] = v;
       barrier();
       double a[IpcShm::kMaxRanks];
       for (int q = 0; q < nranks; ++q) a[q] = shm->red[q][0];
-      ck(hipMemcpyAsync(all, a, sizeof(double) * nranks, hipMemcpyHostToDevice, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+      ck(hipMemcpyAsync(all, a, sizeof(double) * nranks, hipMemcpyHostToDevice, s), "scalars to device"); ck(hipStreamSynchronize(s), "sync");
       barrier();
     } else allgather(my, all, sizeof(double) * count, s);
   }
   void allreduce(double* dev, size_t count, hipStream_t s, bool is_max) {
     if (count > 64) throw ChemError(CHEM_ECOMM, "ipc transport: reduction of more than 64 values");
     double v[64];
-    ck(hipMemcpyAsync(v, dev, count * sizeof(double), hipMemcpyDeviceToHost, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+    ck(hipMemcpyAsync(v, dev, count * sizeof(double), hipMemcpyDeviceToHost, s), "reduction to host"); ck(hipStreamSynchronize(s), "sync");
     for (size_t k = 0; k < count; ++k) shm->red[rank][k] = v[k];
     barrier();
     for (size_t k = 0; k < count; ++k) {
@@ -362,7 +369,7 @@ struct IpcTransport : Transport {
       for (int q = 1; q < nranks; ++q) { const double o = shm->red[q][k]; r = is_max ? (o > r ? o : r) : r + o; }
       v[k] = r;
     }
-    ck(hipMemcpyAsync(dev, v, count * sizeof(double), hipMemcpyHostToDevice, s), "copy"); ck(hipStreamSynchronize(s), "sync");
+    ck(hipMemcpyAsync(dev, v, count * sizeof(double), hipMemcpyHostToDevice, s), "reduction to device"); ck(hipStreamSynchronize(s), "sync");
     barrier();
   }
   void allreduce_max_f64(double* dev, size_t count, hipStream_t s) override { allreduce(dev, count, s, true); }
@@ -373,7 +380,7 @@ struct IpcTransport : Transport {
     barrier();
     for (int q = 0; q < nranks; ++q) {
       void* dst = (char*)out + (size_t)q * bytes;
-      if (q == rank) { if (in != dst && bytes) ck(hipMemcpyAsync(dst, in, bytes, hipMemcpyDeviceToDevice, s), "copy"); }
+      if (q == rank) { if (in != dst && bytes) ck(hipMemcpyAsync(dst, in, bytes, hipMemcpyDeviceToDevice, s), "gather: own share"); }
       else copy_from(q, 0, dst, bytes, nullptr, s);
     }
     ck(hipStreamSynchronize(s), "sync");

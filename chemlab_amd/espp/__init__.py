@@ -20,6 +20,7 @@ import types
 import numpy as np
 
 from ..engine import Engine
+from .. import rank as _rank
 
 _factory = [lambda: Engine(device=0, precision=32)]
 
@@ -778,7 +779,7 @@ class _ATRPActivator(object):
         filename = filename or self.stats_filename
         rows = self.system.engine.atrp_stats()
         if filename:
-            with open(filename, "w") as f:
+            with _rank.wopen(filename, "w") as f:
                 f.write("# step ratio_activator ratio_deactivator activated deactivated candidates selected\n")
                 for r in rows:
                     f.write("%d %.10g %.10g %d %d %d %d\n" % (r["step"], r["ratio_activator"], r["ratio_deactivator"], r["activated"],
@@ -947,7 +948,7 @@ class _ChemicalReaction(object):
     def save_reaction_counters(self, filename):
         """events per reaction index (start_simulation.py:1028)"""
         ev = self.system.engine.get_events()
-        with open(filename, "w") as f:
+        with _rank.wopen(filename, "w") as f:
             for r in range(len(self._reactions)):
                 f.write("%d %d\n" % (r, int((ev["reaction"] == r).sum())))
 
@@ -955,7 +956,7 @@ class _ChemicalReaction(object):
         """events between particles of the same / of different bonded clusters at the time of the event, per reaction
         (start_simulation.py:1034); needs engine option count_intra_inter (the driver sets it)."""
         ev = self.system.engine.get_events()
-        with open(filename, "w") as f:
+        with _rank.wopen(filename, "w") as f:
             f.write("# reaction intra inter\n")
             for r in range(len(self._reactions)):
                 m = ev["reaction"] == r
@@ -987,6 +988,8 @@ class _TopologyManager(object):
         tmp = tempfile.mkdtemp()
         try:
             outputs.write_topology_dumps(os.path.join(tmp, "x"), self.system, self._fpls)
+            if not _rank.is_root():      # (the dump above gathers collectively: every rank makes it, rank 0 keeps the file)
+                return
             d = os.path.dirname(filename)
             if d and not os.path.isdir(d):
                 os.makedirs(d)
@@ -1158,7 +1161,7 @@ class _SystemMonitorOutputCSV(object):
         self._header_written = False
 
     def write(self, names, row):
-        with open(self.filename, "a") as f:
+        with _rank.wopen(self.filename, "a") as f:
             if not self._header_written:
                 f.write(self.delimiter.join(names) + "\n")
                 self._header_written = True
@@ -1233,7 +1236,7 @@ class _DumpGRO(object):
         ids, pos = e.get_state("ID"), e.get_state("POS_UNFOLDED" if self.unfolded else "POS")
         vel, types, res = e.get_state("VEL"), e.get_state("TYPE"), e.get_state("RESID")
         box = list(self.system.bc.boxL)
-        with open(self.filename, "a" if self.append else "w") as f:
+        with _rank.wopen(self.filename, "a" if self.append else "w") as f:
             f.write("system size %d\n%d\n" % (len(ids), len(ids)))
             for k in range(len(ids)):
                 f.write("%5d%-5s%5s%5d%8.3f%8.3f%8.3f%8.4f%8.4f%8.4f\n" % (int(res[k]) % 100000, "T%d" % types[k], "T%d" % types[k], int(ids[k]) % 100000,
@@ -1313,6 +1316,8 @@ class _DumpH5MD(object):
 
     def flush(self):
         tree = self.tree()
+        if not _rank.is_root():
+            return self.filename
         try:
             import h5py
         except ImportError:

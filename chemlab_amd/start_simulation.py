@@ -18,6 +18,7 @@ import sys
 import time
 
 from . import espp as espressopp
+from . import rank
 from .chemlab import app_args, files_io, gromacs_topology, outputs, reaction_parser, reaction_setup
 
 
@@ -136,14 +137,31 @@ def write_final_outputs(args, system, gt, conf, bonded, angles, dihedrals, chem_
     espressopp.io.DumpGRO(system, system.integrator, filename=prefix + "_whole_confout.gro").dump()
     if ar is not None:
         ar.save_reaction_counters(prefix + "_reaction_counters")
-        with open(prefix + "_reaction_counters", "a") as f:
+        with rank.wopen(prefix + "_reaction_counters", "a") as f:
             f.write("\n\nReaction index\n")
             for ridx in sorted(reaction_index):
                 f.write("%s %s\n" % (ridx, reaction_index[ridx]))
         ar.save_intra_inter_counter(prefix + "_intra_inter_counters")
 
 
-def main(argv=None, hooks=None, quiet=False):
+def join_ranks(precision=32):
+    """Started as `python -m torch.distributed.run --nproc-per-node N -m chemlab_amd.start_simulation @params` (the reference:
+    `mpirun -n N`, node grid from the communicator size, start_simulation.py:152-163): every rank runs the driver, its engine
+    is joined to the slab decomposition (RCCL over xGMI; hipIpc where ranks share a device), rank 0 writes the outputs.
+    Returns (rank, world); (0, 1) when started plainly."""
+    world, rk = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world <= 1:
+        return 0, 1
+    from . import multigpu
+    eng, _ = multigpu.make_engine(rk, int(os.environ.get("LOCAL_RANK", str(rk))), world, precision)
+    espressopp.set_engine_factory(lambda: eng)
+    rank.set_root(rk == 0)
+    return rk, world
+
+
+def main(argv=None, hooks=None, quiet=False, ranks=None):
+    rk, world = ranks if ranks is not None else (0, 1)
+    quiet = quiet or rk != 0
     log = (lambda *a: None) if quiet else print
     parser = app_args._args()
     args = parser.parse_args(argv)
@@ -173,7 +191,7 @@ def main(argv=None, hooks=None, quiet=False):
     system = espressopp.System()
     system.rng = espressopp.esutil.RNG(rng_seed)
     system.skin = skin
-    node_grid = [int(x) for x in args.node_grid.split(",")] if args.node_grid else espressopp.tools.decomp.nodeGrid(1)
+    node_grid = [int(x) for x in args.node_grid.split(",")] if args.node_grid else espressopp.tools.decomp.nodeGrid(world)
     cell_grid = espressopp.tools.decomp.cellGrid(box, node_grid, max_cutoff, skin)
     log("Cell grid: (%d, %d, %d)" % tuple(int(c) for c in cell_grid))
     system.bc = espressopp.bc.OrthorhombicBC(system.rng, box)
@@ -207,7 +225,8 @@ def main(argv=None, hooks=None, quiet=False):
         dynamic_types = sc.dynamic_types
         reaction_index = {k: cr["equation"] for k, cr in enumerate(c for g in rc["reactions"].values() for c in g["reaction_list"])}
         system.engine.set_option("count_intra_inter", 1)   # ar.save_intra_inter_counter at the end of the run
-        shutil.copyfile(args.reactions, "%s_%s_%s" % (args.output_prefix, rng_seed, os.path.basename(args.reactions)))
+        if rank.is_root():
+            shutil.copyfile(args.reactions, "%s_%s_%s" % (args.output_prefix, rng_seed, os.path.basename(args.reactions)))
         cr_interval = rc["general"]["interval"]
         cad = cadence(args, cr_interval)
         log("Change integrator step to %d" % cad["integrator_step"])
@@ -367,7 +386,7 @@ def main(argv=None, hooks=None, quiet=False):
         if hasattr(ext, "save_stats"):
             ext.save_stats()                                  # ATRPActivator.stats_filename (reaction_post_process.py:390-396)
     npart = espressopp.analysis.NPart(system).compute()
-    with open("%s_%s_benchmark.csv" % (args.output_prefix, rng_seed), "a+") as f:
+    with rank.wopen("%s_%s_benchmark.csv" % (args.output_prefix, rng_seed), "a+") as f:
         f.write("%d %d %s %s\n" % (1, npart, total_time, integrator_loop))
     log("finished: %d steps, integratorLoop %.3f s, %.1f steps/s" % (cad["sim_step"] * cad["integrator_step"], integrator_loop,
                                                                        cad["sim_step"] * cad["integrator_step"] / max(integrator_loop, 1e-12)))
@@ -377,4 +396,4 @@ def main(argv=None, hooks=None, quiet=False):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    main(sys.argv[1:], ranks=join_ranks())

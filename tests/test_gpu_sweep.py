@@ -512,3 +512,82 @@ def test_reaction_extensions_on_slabs(make_gpu, make_oracle, P):
         assert np.array_equal(res["ty"], o.get_state("TYPE")) and (res["ty"] == PL).sum() > 0 and (res["ty"] == PA).sum() > 0
         assert np.array_equal(res["st"], o.get_state("STATE")) and np.allclose(res["m"], o.get_state("MASS"))
         assert rel_err(res["x"], o.get_state("POS_UNFOLDED")) < 1e-8
+
+
+def _replicated_chain_growth(dst, k=2):
+    """examples/chain_growth_catalytic (1500 beads, box 12.1: four cells per axis, too few for slabs) replicated k x k x k."""
+    import os, shutil
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "chain_growth_catalytic")
+    shutil.copytree(gold, dst)
+    lines = open(os.path.join(gold, "conf.gro")).read().splitlines()
+    n0 = int(lines[1])
+    atoms, box = lines[2:2 + n0], [float(v) for v in lines[2 + n0].split()]
+    out, idx = [], 0
+    for sx in range(k):
+        for sy in range(k):
+            for sz in range(k):
+                for a in atoms:
+                    idx += 1
+                    x, y, z = float(a[20:28]) + sx * box[0], float(a[28:36]) + sy * box[1], float(a[36:44]) + sz * box[2]
+                    out.append("%5d%s%5d%8.3f%8.3f%8.3f" % (idx % 100000, a[5:15], idx % 100000, x, y, z))
+    with open(os.path.join(dst, "conf.gro"), "w") as f:
+        f.write("\n".join([lines[0], str(len(out))] + out + ["%10.5f%10.5f%10.5f" % tuple(k * b for b in box)]) + "\n")
+    top = open(os.path.join(gold, "topol.top")).read()
+    assert "MOL             750" in top
+    with open(os.path.join(dst, "topol.top"), "w") as f:
+        f.write(top.replace("MOL             750", "MOL             %d" % (750 * k ** 3)))
+
+
+def test_driver_on_two_ranks_over_ipc_on_one_gpu(tmp_path):
+    """The driver the way the reference is started on several processes (`mpirun -n N python start_simulation.py @params`,
+    node grid from the communicator size: start_simulation.py:152-163) -- here `python -m torch.distributed.run
+    --nproc-per-node 2 -m chemlab_amd.start_simulation @params`: every rank runs the driver, the engines form two slabs
+    (hipIpc transport: both ranks share the one leased GPU), rank 0 alone writes the outputs.  Against the same run on one
+    process: same files, same bonds (fp32 on both sides; identical discrete outcomes over this short run), same invariant
+    of Checkup.ipynb (no A bead with more than three chain bonds)."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # (options go into the params file: torch.distributed.run's own parser claims anything that abbreviates one of its options,
+    #  `--run=1500` "could match --run-path")
+    argv = ["@params"]
+    over = dict(run=1500, start_ar=500, int_step=500, trj_collect=500, energy_collect=500)
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    files = {}
+    for name in ("one", "two"):
+        d = str(tmp_path / name)
+        _replicated_chain_growth(d)
+        par = [l for l in open(os.path.join(d, "params")).read().splitlines() if l.split("=")[0] not in over]
+        with open(os.path.join(d, "params"), "w") as f:
+            f.write("\n".join(par + ["%s=%s" % kv for kv in over.items()]) + "\n")
+        if name == "one":
+            cmd = [sys.executable, "-m", "chemlab_amd.start_simulation"] + argv
+            e = env
+        else:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), "-m", "chemlab_amd.start_simulation"] + argv
+            e = dict(env, CHEM_TRANSPORT="ipc", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=e, cwd=d)
+        if res.returncode != 0 and os.path.isdir(os.path.join(root, "gpurun_out")):      # (pytest shortens long assertion messages)
+            with open(os.path.join(root, "gpurun_out", "driver_%s_ranks.err" % name), "w") as f:
+                f.write(res.stdout + "\n----\n" + res.stderr)
+        assert res.returncode == 0, (name, res.stdout[-1500:], res.stderr[-3000:])
+        files[name] = sorted(os.listdir(d))
+        if name == "two":
+            assert res.stdout.count("Cell grid:") == 1                       # one rank talks
+    assert files["one"] == files["two"], (set(files["one"]) ^ set(files["two"]))
+    rows = {}
+    for name in ("one", "two"):
+        bf = [f for f in files[name] if f.endswith("_bonds.dat")]
+        assert len(bf) == 1
+        r = [[int(v) for v in l.split()[:2]] for l in open(str(tmp_path / name / bf[0])) if l.strip() and l.split()[0].isdigit()]
+        rows[name] = np.asarray(r, dtype=np.int64).reshape(-1, 2)
+    assert len(rows["one"]) > 200
+    deg = np.bincount(rows["two"][:, :2].ravel())
+    assert set(np.unique(deg).tolist()) <= {0, 1, 2, 3}
+    same = np.array_equal(rows["one"], rows["two"])
+    assert same or abs(len(rows["one"]) - len(rows["two"])) <= 0.05 * len(rows["one"]), (len(rows["one"]), len(rows["two"]))
