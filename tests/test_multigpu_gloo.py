@@ -84,3 +84,29 @@ def test_bench_started_plainly_spawns_its_ranks(tmp_path):
     import torch
     if not torch.cuda.is_available():
         assert bad.returncode != 0
+
+
+def test_only_the_root_rank_writes(tmp_path):
+    """Multi-process driver runs (chemlab_amd/rank.py): every writer opens its files through wopen -- the real file on rank 0,
+    the null device elsewhere; reads always pass through.  Started plainly, join_ranks() reports a world of one."""
+    import os
+    from chemlab_amd import rank, start_simulation
+    p = str(tmp_path / "out.txt")
+    try:
+        rank.set_root(False)
+        with rank.wopen(p, "w") as f:
+            f.write("x")
+        assert not os.path.exists(p) and not rank.is_root()
+        rank.set_root(True)
+        with rank.wopen(p, "a") as f:
+            f.write("y")
+        rank.set_root(False)
+        with rank.wopen(p) as f:                       # reading is never redirected
+            assert f.read() == "y"
+    finally:
+        rank.set_root(True)
+    env = {k: os.environ.pop(k) for k in ("WORLD_SIZE", "RANK") if k in os.environ}
+    try:
+        assert start_simulation.join_ranks() == (0, 1)
+    finally:
+        os.environ.update(env)
