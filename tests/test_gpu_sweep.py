@@ -591,3 +591,52 @@ def test_driver_on_two_ranks_over_ipc_on_one_gpu(tmp_path):
     assert set(np.unique(deg).tolist()) <= {0, 1, 2, 3}
     same = np.array_equal(rows["one"], rows["two"])
     assert same or abs(len(rows["one"]) - len(rows["two"])) <= 0.05 * len(rows["one"]), (len(rows["one"]), len(rows["two"]))
+
+
+@pytest.mark.parametrize("case", range(8))
+def test_random_tetramers_with_every_bonded_family(make_gpu, make_oracle, case):
+    """Four-bead molecules on a random lattice with FENE bonds, cosine angles, n-cosine, Ryckaert-Bellemans and tabulated
+    dihedrals (gromacs_topology.py:949-961,1086-1096,1206-1224) and full 1-2/1-3/1-4 exclusions: forces, list energies and a
+    short trajectory against the oracle, single domain or one slab, fp64 or fp32."""
+    rng = np.random.default_rng(23000 + case)
+    k = int(rng.integers(5, 11))                       # 125 .. 1000 molecules
+    nm = k ** 3
+    cell = float(rng.uniform(3.6, 4.6))
+    base = np.stack(np.meshgrid(np.arange(k), np.arange(k), np.arange(k), indexing="ij"), -1).reshape(-1, 3) * cell + 1.0
+    off = np.array([[0, 0, 0], [0.9, 0.2, 0.1], [1.2, 1.1, 0.4], [2.1, 1.3, 1.2]])
+    pos = (base[:, None, :] + off[None]).reshape(-1, 3) + rng.uniform(-0.05, 0.05, (4 * nm, 3))
+    n = 4 * nm
+    ids = np.arange(1, n + 1).reshape(nm, 4)
+    prec = 64 if rng.random() < 0.6 else 32
+    spec = dict(n=n, box=[k * cell] * 3, rc=2.5, skin=float(rng.uniform(0.2, 0.4)), dt=0.002, ids=np.arange(1, n + 1), types=np.zeros(n, np.int32),
+                pos=pos, vel=rng.normal(0, 0.3, (n, 3)), mass=np.ones(n), lj=[(0, 0, 0.2, 0.8, 2.5)], kT=1.0, gamma=0.0, seed=1,
+                rebuild_criterion=int(rng.integers(0, 2)),
+                lists=[dict(arity=2, kind="FENE", params=[30.0, 0.0, 2.5], ids=np.concatenate([ids[:, [0, 1]], ids[:, [1, 2]], ids[:, [2, 3]]])),
+                       dict(arity=3, kind="ANG_COSINE", params=[2.0, np.deg2rad(130)], ids=np.concatenate([ids[:, [0, 1, 2]], ids[:, [1, 2, 3]]])),
+                       dict(arity=4, kind="DIH_NCOS", params=[1.5, np.deg2rad(20), 3.0], ids=ids),
+                       dict(arity=4, kind="DIH_RB", params=[0.5, -0.3, 0.2, 0.1, -0.1, 0.05], ids=ids[::2])],
+                exclusions=np.concatenate([ids[:, [0, 1]], ids[:, [1, 2]], ids[:, [2, 3]], ids[:, [0, 2]], ids[:, [1, 3]], ids[:, [0, 3]]]))
+    opts = {}
+    if rng.random() < 0.5:
+        opts["dd_self"] = 1
+    if rng.random() < 0.25:
+        opts["fused_rebuild"] = 0
+    g, o = make_gpu(prec), make_oracle()
+    _apply_opts(g, opts)
+    dphi = 2 * np.pi / 720
+    phi = -np.pi + dphi * np.arange(721)
+    for eng in (g, o):
+        W.apply(spec, eng, thermostat=False)
+        h = eng.list_create(4, "DIH_TABULATED")
+        eng.list_set_params(h, [eng.table_create(phi[0], dphi, 0.8 * (1 + np.cos(2 * phi - 0.3)), 1.6 * np.sin(2 * phi - 0.3))])
+        eng.list_add(h, ids[::3])
+    try:
+        g.run(0)
+    except Exception as e:
+        _refused(e, case, opts)
+    o.run(0)
+    assert rel_err(g.get_state("FORCE"), o.get_state("FORCE")) < (1e-10 if prec == 64 else 5e-5), (case, opts, prec)
+    og, oo = g.observe(), o.observe()
+    assert np.allclose(og["epot_list"], oo["epot_list"], rtol=1e-11 if prec == 64 else 2e-4, atol=0 if prec == 64 else 1e-3), (case, opts)
+    g.run(50); o.run(50)
+    assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 2e-4), (case, opts, prec)
