@@ -640,3 +640,52 @@ def test_random_tetramers_with_every_bonded_family(make_gpu, make_oracle, case):
     assert np.allclose(og["epot_list"], oo["epot_list"], rtol=1e-11 if prec == 64 else 2e-4, atol=0 if prec == 64 else 1e-3), (case, opts)
     g.run(50); o.run(50)
     assert rel_err(g.get_state("POS_UNFOLDED"), o.get_state("POS_UNFOLDED")) < (1e-9 if prec == 64 else 2e-4), (case, opts, prec)
+
+
+@pytest.mark.parametrize("case", range(6))
+def test_random_reactive_system_on_several_ranks(make_gpu, make_oracle, case):
+    """Random reactive melts on two to four slabs (ranks as threads): uneven layer counts per rank, orthorhombic boxes, list
+    skins and both bond modes -- events, bonds, states and trajectory of the single-domain oracle on every rank (fp64)."""
+    rng = np.random.default_rng(29000 + case)
+    P = int(rng.integers(2, 5))
+    n = int(rng.choice([k ** 3 for k in range(20, 33, 2)] + [4 * k ** 3 for k in range(13, 19)]))
+    iv = int(rng.integers(4, 12))
+    spec = W.reactive_melt(n=n, rho=float(rng.uniform(0.6, 0.95)), rc=2.5, skin=float(rng.uniform(0.2, 0.45)), seed=800 + case, interval=iv)
+    a = float(rng.uniform(0.85, 1.1)); b = float(rng.uniform(0.85, 1.1))
+    _stretch(spec, [a, b, 1.0 / (a * b)])            # (z is the stretched axis as often as not: more or fewer layers per rank)
+    for r in spec["reaction"]["reactions"]:
+        r["rate"] = 1e9
+    spec["rebuild_criterion"] = int(rng.integers(0, 2))
+    opts = {}
+    if rng.random() < 0.5:
+        opts["list_skin"] = spec["skin"] + float(rng.uniform(0.0, 0.25))
+    if rng.random() < 0.4:
+        opts["bond_pass"] = 0
+    if rng.random() < 0.25:
+        opts["dd_fold"] = 0
+    o = make_oracle()
+    ho = W.apply(spec, o)
+    for _ in range(4):
+        o.run(iv)
+    hh = {}
+
+    def setup(g):
+        for k_, v_ in opts.items():
+            g.set_option(k_, v_)
+        hh["h"] = W.apply(spec, g)
+
+    def run(g):
+        for _ in range(4):
+            g.run(iv)
+        return dict(ev=[e[:4] for e in sorted_events(g.get_events())], bonds=g.get_list(hh["h"]["reaction_bonds"]), st=g.get_state("STATE"),
+                    x=g.get_state("POS_UNFOLDED"))
+    try:
+        out = _ranks_or_self(make_gpu, P, setup, run)
+    except Exception as e:
+        _refused(e, case, opts)
+    eo = [e[:4] for e in sorted_events(o.get_events())]
+    assert len(eo) > 500
+    for res in out:
+        assert res["ev"] == eo, (case, P, opts)
+        assert np.array_equal(res["bonds"], o.get_list(ho["reaction_bonds"])) and np.array_equal(res["st"], o.get_state("STATE"))
+        assert rel_err(res["x"], o.get_state("POS_UNFOLDED")) < 1e-8, (case, P, opts)
