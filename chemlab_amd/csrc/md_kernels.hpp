@@ -35,7 +35,10 @@ __device__ __forceinline__ double rcp_r(double x) { return 1.0 / x; }
 __device__ __forceinline__ double floor_r(double x) { return floor(x); }
 
 constexpr int kMaxTypes = CHEM_MAX_TYPES;
-constexpr int kIntPerBlock = 512;   // particles per workgroup of k_integrate (= entries of the blockmax array per 512 particles)
+#ifndef CHEM_INT_PER_BLOCK
+#define CHEM_INT_PER_BLOCK 512
+#endif
+constexpr int kIntPerBlock = CHEM_INT_PER_BLOCK;   // particles per workgroup of k_integrate (= entries of the blockmax array per 512 particles)
 constexpr int kWave = 64;
 
 // ---- device-resident control block (one per context) ---------------------------------
