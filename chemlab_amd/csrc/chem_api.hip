@@ -313,7 +313,9 @@ template <typename R> struct CtxT : Ctx {
   DBuf<double> dd_vals;
   DBuf<unsigned long long> foldmax;    // decomposed path: atomic fold of the step's displacement maxima (kFoldSlots words, md_kernels.hpp)
   bool fold_on() const { return dd_merged() && opt_dd_fold; }
-  unsigned long long* fold_arg() { return (dd_on && fold_on()) ? foldmax.p : nullptr; }
+  // (allocated here if need be: the first drift of a context runs before its first dd_step_sync, and a launch without the words
+  //  would leave that step's displacement out of the accumulated distance)
+  unsigned long long* fold_arg() { if (!(dd_on && fold_on())) return nullptr; ensure_hflag(); return foldmax.p; }
   DBuf<int> gtag;                      // slab: index of a tag's ghost copy on this rank (-1: none)
   DBuf<Box<R>> box_dev; Box<R> box_dev_host; bool box_dev_valid = false;   // device copy of the box for the standalone list kernel
   int S = 0;

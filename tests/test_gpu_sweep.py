@@ -689,3 +689,29 @@ def test_random_reactive_system_on_several_ranks(make_gpu, make_oracle, case):
         assert res["ev"] == eo, (case, P, opts)
         assert np.array_equal(res["bonds"], o.get_list(ho["reaction_bonds"])) and np.array_equal(res["st"], o.get_state("STATE"))
         assert rel_err(res["x"], o.get_state("POS_UNFOLDED")) < 1e-8, (case, P, opts)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_first_drift_of_a_slab_context_counts_towards_the_rebuild(make_gpu, make_oracle, seed):
+    """A tight skin (rebuild every second step): the displacement of the very first drift of a fresh slab context must be in
+    the accumulated distance -- the atomic fold of the integrate kernel once ran before its words were allocated and left
+    that step out.  Rebuild counts after every single step against the oracle's, with the fold on and off."""
+    spec = W.lj_melt(n=8788, seed=seed, jitter=0.05, kT=1.5, skin=0.06)
+    spec["rebuild_criterion"] = 0
+    o = make_oracle()
+    W.apply(spec, o, thermostat=False)
+    ref = []
+    for _ in range(6):
+        o.run(1)
+        ref.append(o.timers()["rebuilds"])
+    assert ref[-1] - ref[0] >= 2                       # the skin is tight enough for this to be a test
+    for fold in (1, 0):
+        g = make_gpu(64)
+        g.set_option("dd_self", 1)
+        g.set_option("dd_fold", fold)
+        W.apply(spec, g, thermostat=False)
+        got = []
+        for _ in range(6):
+            g.run(1)
+            got.append(g.timers()["rebuilds"])
+        assert got == ref, (seed, fold, got, ref)
