@@ -1054,9 +1054,8 @@ template <typename R> struct CtxT : Ctx {
     hipLaunchKernelGGL(k_sort_gather<R>, dim3(std::min(cdiv(box.ncell, 4), 2048)), dim3(256), 0, stream, box.ncell, cell_start.p, perm.p,
                        x4.p, v4.p, tag.p, img4.p, x4o.p, v4o.p, tago.p, img4o.p, c, box, cell_sub.p);
     // the ghost layers are filled by the neighbours' particles afterwards: no sub-bin information for their cells
-    hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nxy, 256)), dim3(256), 0, stream, cell_sub.p, -1, (size_t)nxy);
-    hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nxy, 256)), dim3(256), 0, stream, cell_sub.p + (size_t)(ncz + 1) * nxy, -1, (size_t)nxy);
-    hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nglob, 256)), dim3(256), 0, stream, rtag.p, -1, (size_t)nglob);
+    if (gtag.n < (size_t)nglob) gtag.alloc(nglob);
+    hipLaunchKernelGGL(k_dd_clear, dim3(cdiv(std::max(nglob, nxy), 256)), dim3(256), 0, stream, rtag.p, gtag.p, nglob, cell_sub.p, cell_sub.p + (size_t)(ncz + 1) * nxy, nxy);
     hipLaunchKernelGGL(k_copyback<R>, dim3(nb), dim3(256), 0, stream, cell_start.p, nxy, (ncz + 1) * nxy, x4o.p, v4o.p, tago.p, img4o.p, x4.p, v4.p, tag.p, img4.p, rtag.p, x0.p, c);
     // 5. boundary-layer counts to the neighbours
     lcnt_dn.alloc(nxy + 1); lcnt_up.alloc(nxy + 1); gcnt_lo.alloc(nxy + 1); gcnt_up.alloc(nxy + 1);
@@ -1079,10 +1078,7 @@ template <typename R> struct CtxT : Ctx {
                   Transport::Msg{tag.p + halo_dn_off, halo_dn_cnt * sizeof(int), tag.p + halo_up_off, halo_up_cnt * sizeof(int), tag.p + G + n, ngup * sizeof(int),
                                  tag.p + G - nglo, nglo * sizeof(int)}, lower, upper, stream);
     hipLaunchKernelGGL(k_ghost_cells, dim3(1), dim3(1024), 0, stream, nxy, ncz, gcnt_lo.p, gcnt_up.p, cell_start.p);
-    if (gtag.n < (size_t)nglob) gtag.alloc(nglob);
-    hipLaunchKernelGGL(k_fill<int>, dim3(cdiv(nglob, 256)), dim3(256), 0, stream, gtag.p, -1, (size_t)nglob);
-    if (nglo) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(nglo, 256)), dim3(256), 0, stream, G - nglo, nglo, tag.p, rtag.p, gtag.p);
-    if (ngup) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(ngup, 256)), dim3(256), 0, stream, G + n, ngup, tag.p, rtag.p, gtag.p);
+    if (nglo + ngup) hipLaunchKernelGGL(k_ghost_rtag, dim3(cdiv(nglo + ngup, 256)), dim3(256), 0, stream, G - nglo, nglo, G + n, ngup, tag.p, rtag.p, gtag.p);
     // 7. tiles + lists over the own layers.  A stencil beyond the LDS tile capacity or a row beyond its stride is a LOCAL matter
     //    (both capacities are per rank, no collective depends on them): grow and build the lists again, here, instead of
     //    carrying the flag to the end of the call and failing there (tests/test_gpu_sweep.py: a trimer melt at rho = 0.3

@@ -787,13 +787,22 @@ __global__ __launch_bounds__(1024) void k_ghost_cells(int nxy, int own_layers, c
 }
 
 // rtag for ghost copies (only where the particle is not owned here)
-// gtag: the ghost copy of every tag that has one here, owned or not (a one-rank slab holds a real particle AND its ghost)
-__global__ __launch_bounds__(256) void k_ghost_rtag(int g0, int ng, const int* __restrict__ tag, int* __restrict__ rtag, int* __restrict__ gtag) {
+// gtag: the ghost copy of every tag that has one here, owned or not (a one-rank slab holds a real particle AND its ghost).
+// One launch for both ghost ranges: [g0a, g0a + nga) in front of the reals, [g0b, g0b + ngb) behind them.
+__global__ __launch_bounds__(256) void k_ghost_rtag(int g0a, int nga, int g0b, int ngb, const int* __restrict__ tag, int* __restrict__ rtag, int* __restrict__ gtag) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= ng) return;
-  const int t = tag[g0 + k];
-  atomicCAS(&rtag[t], -1, g0 + k);
-  gtag[t] = g0 + k;
+  if (k >= nga + ngb) return;
+  const int g = k < nga ? g0a + k : g0b + (k - nga);
+  const int t = tag[g];
+  atomicCAS(&rtag[t], -1, g);
+  gtag[t] = g;
+}
+// what a slab rebuild clears before the sorted copies come back: the tag maps, and the x sub-bin words of the two ghost
+// layers (filled by the neighbours' particles afterwards: no sub-bin information for their cells) -- one launch
+__global__ __launch_bounds__(256) void k_dd_clear(int* __restrict__ rtag, int* __restrict__ gtag, int nglob, int* __restrict__ sub_lo, int* __restrict__ sub_hi, int nxy) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nglob) { rtag[k] = -1; gtag[k] = -1; }
+  if (k < nxy) { sub_lo[k] = -1; sub_hi[k] = -1; }
 }
 
 // =======================================================================================
