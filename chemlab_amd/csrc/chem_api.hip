@@ -1027,10 +1027,9 @@ template <typename R> struct CtxT : Ctx {
   void rebuild_dd() {
     Trace trd("dd");
     const int nxy = box.nc[0] * box.nc[1];
-    set_need_rebuild_async(1);
-    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)&ctl.p->force_rebuild, 0, 1, stream));   // the request is being served (the force kernel's decision only reads it)
+    // (need_rebuild on, force_rebuild off: the request is being served; migration headers cleared)
+    hipLaunchKernelGGL(k_dd_begin, dim3(1), dim3(64), 0, stream, ctl.p, reinterpret_cast<int*>(mig[0].p), reinterpret_cast<int*>(mig[1].p));
     // 1. bin the reals; leavers go to the migration buffers
-    HIPCHK(hipMemsetAsync(mig[0].p, 0, 16, stream)); HIPCHK(hipMemsetAsync(mig[1].p, 0, 16, stream));
     launch_sort_chain(G, n);
     // 2. migration exchange (fixed-capacity buffers, count in the header)
     tr->exchange(mig[0].p, mig_bytes(), mig[1].p, mig_bytes(), mig[2].p, mig_bytes(), mig[3].p, mig_bytes(), lower, upper, stream);

@@ -797,6 +797,13 @@ __global__ __launch_bounds__(256) void k_ghost_rtag(int g0a, int nga, int g0b, i
   atomicCAS(&rtag[t], -1, g);
   gtag[t] = g;
 }
+// first launch of a slab rebuild: the request is being served (need_rebuild on for the chain's kernels, force_rebuild off -- the
+// force kernel's decision only reads it), headers of the two migration buffers cleared -- one launch instead of four memsets
+__global__ void k_dd_begin(DevCtl* ctl, int* __restrict__ mig_dn, int* __restrict__ mig_up) {
+  const int t = threadIdx.x;
+  if (t == 0) { ctl->need_rebuild = 1; ctl->force_rebuild = 0; }
+  if (t < 4) { mig_dn[t] = 0; mig_up[t] = 0; }
+}
 // what a slab rebuild clears before the sorted copies come back: the tag maps, and the x sub-bin words of the two ghost
 // layers (filled by the neighbours' particles afterwards: no sub-bin information for their cells) -- one launch
 __global__ __launch_bounds__(256) void k_dd_clear(int* __restrict__ rtag, int* __restrict__ gtag, int nglob, int* __restrict__ sub_lo, int* __restrict__ sub_hi, int nxy) {
